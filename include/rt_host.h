@@ -1,0 +1,65 @@
+/*
+ * rt_host.h — C ABI of the host-side ingest library (librt_host.so).
+ *
+ * In the reference the host work is done by the Rust crate itself: scene-file
+ * parsing (/root/reference/src/config.rs), OBJ/MTL loading (src/obj.rs), the
+ * P6 texture loader (src/material.rs:150-189), the binned-SAH BVH builder
+ * (src/bvh.rs:46-224) and the mmap'd output image (src/mmap.rs, src/lib.rs:
+ * 64-89).  A Rust host keeps all of that and only needs rt_mi355.h.  This
+ * library is the same work written in C++ for hosts without that crate (the
+ * CLI, the Python bindings and the tests of this repository); it produces
+ * exactly the RtSceneDesc / RtRenderParams a Rust host would hand over.
+ * No GPU code, no dependency on HIP.
+ */
+#ifndef RT_HOST_H
+#define RT_HOST_H
+
+#include "rt_mi355.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct RthScene RthScene;
+
+/* `config::parse`, /root/reference/src/config.rs:15-145.  `text` is the scene
+ * file's content; `base_dir` is the directory `obj/...` paths are resolved
+ * against (the reference resolves them against the process's working
+ * directory, /root/reference/src/config.rs:97).  On failure returns NULL and
+ * copies a message into `err` (the reference panics instead). */
+RthScene* rth_parse_scene(const char* text, const char* base_dir, char* err, size_t err_len);
+void rth_free_scene(RthScene* scene);
+
+/* Views into the parsed scene; valid until rth_free_scene. */
+void rth_scene_desc(const RthScene* scene, RtSceneDesc* out);
+void rth_scene_params(const RthScene* scene, RtRenderParams* out);
+
+/* `BvhNode::new`, /root/reference/src/bvh.rs:48-68, for each shape family.
+ * Permutes `shapes` in place exactly as the reference does and returns a
+ * malloc'd node array (free with rth_free) and its length. */
+RtNode* rth_build_bvh_spheres(RtSphere* shapes, uint32_t n, uint32_t* n_nodes);
+RtNode* rth_build_bvh_planes(RtPlane* shapes, uint32_t n, uint32_t* n_nodes);
+RtNode* rth_build_bvh_triangles(RtTriangle* shapes, uint32_t n, uint32_t* n_nodes);
+void rth_free(void* p);
+
+/* `ColorKind::texture_from_ppm_p6`, /root/reference/src/material.rs:150-189.
+ * Returns malloc'd packed RGB8 texels (free with rth_free) or NULL. */
+uint8_t* rth_load_ppm_p6(const char* path, uint32_t* width, uint32_t* height, char* err,
+                         size_t err_len);
+
+/* `Image::new` + `MmapFile::new`, /root/reference/src/lib.rs:70-83 and
+ * /root/reference/src/mmap.rs:41-77: open (create, never truncate) `path`,
+ * size it to header + width*height*3, map it shared, write the P6 header.
+ * Existing pixel bytes are preserved — that is the reference's checkpoint. */
+typedef struct RthImage RthImage;
+RthImage* rth_image_open(const char* path, uint32_t width, uint32_t height, char* err,
+                         size_t err_len);
+uint8_t* rth_image_pixels(RthImage* image); /* width*height*3 bytes after the header */
+size_t rth_image_header_len(const RthImage* image);
+void rth_image_flush(RthImage* image);
+void rth_image_close(RthImage* image);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HOST_H */

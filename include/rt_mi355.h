@@ -1,0 +1,282 @@
+/*
+ * rt_mi355.h — C ABI of the MI355X render-loop library (librt_mi355.so).
+ *
+ * This is the seam a host program binds instead of calling the reference's
+ * `Scene::render` (/root/reference/src/lib.rs:188).  The host keeps scene
+ * parsing, OBJ/MTL/PPM loading and BVH construction and hands the finished,
+ * immutable scene over as flat little-endian f32/u32 arrays (RtSceneDesc);
+ * the library owns everything from ray generation to the quantised pixels.
+ *
+ * Conventions
+ *   - every function returns RT_OK (0) or a negative RtStatus; the message
+ *     for the last failure on a context is available from rt_last_error();
+ *     nothing aborts and nothing throws across this boundary;
+ *   - the caller owns every pointer it passes in; rt_upload_scene copies, so
+ *     the arrays may be freed as soon as it returns;
+ *   - a context is single-caller (not re-entrant) and bound to one GPU;
+ *   - all structs are plain C, naturally aligned, no padding surprises:
+ *     every field is 4 bytes wide except the 8-byte ones, which sit at
+ *     8-byte offsets.
+ */
+#ifndef RT_MI355_H
+#define RT_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1u
+
+/* Leaf marker in RtNode.b, "absent" marker for optional per-triangle tables. */
+#define RT_LEAF_BIT 0x80000000u
+#define RT_NO_INDEX 0xFFFFFFFFu
+
+/* Seed of the reference's generator, /root/reference/src/rng.rs:10. */
+#define RT_RNG_SEED 0x0ef6f79ed30ba75aull
+
+typedef enum RtStatus {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,   /* bad argument / inconsistent scene description   */
+    RT_ERR_NO_DEVICE = -2, /* no usable GPU (the library never falls back)     */
+    RT_ERR_HIP = -3,       /* a HIP runtime call failed                        */
+    RT_ERR_OOM = -4,       /* device or host allocation failed                 */
+    RT_ERR_STATE = -5      /* call order (e.g. render before upload)           */
+} RtStatus;
+
+/* MaterialKind, /root/reference/src/material.rs:113-119. */
+typedef enum RtMaterialKind {
+    RT_MAT_LAMBERTIAN = 0,
+    RT_MAT_METAL = 1, /* param = fuzziness        */
+    RT_MAT_GLASS = 2, /* param = refractive index */
+    RT_MAT_LIGHT = 3
+} RtMaterialKind;
+
+/* ColorKind, /root/reference/src/material.rs:140-148. */
+typedef enum RtColorKind { RT_COLOR_SOLID = 0, RT_COLOR_TEXTURE = 1 } RtColorKind;
+
+/* Shape families in the order `ray_color` consults them,
+ * /root/reference/src/lib.rs:314-333 (first wins on equal distance). */
+typedef enum RtShapeKind {
+    RT_SHAPE_SPHERE = 0,
+    RT_SHAPE_PLANE = 1,
+    RT_SHAPE_TRIANGLE = 2,
+    RT_SHAPE_NONE = 3
+} RtShapeKind;
+
+/* How pseudo-random draws are assigned to samples. */
+typedef enum RtRngMode {
+    /* One wyrand substream per (sample, pixel): stream k = sample*W*H + y*W + x
+     * starts at state seed + k*(2+3*max_bounces)*0x2d358dccaa6c78a5 (mod 2^64),
+     * i.e. a jump inside the reference's single Weyl sequence.  The only mode
+     * the GPU implements; results do not depend on GPU count or scheduling. */
+    RT_RNG_SUBSTREAM = 0,
+    /* One stream consumed in the literal order of the reference running on a
+     * single thread (/root/reference/src/lib.rs:226-296).  CPU oracle only. */
+    RT_RNG_SERIAL = 1
+} RtRngMode;
+
+/* BvhNode + BvhNodeKind, /root/reference/src/bvh.rs:15-21,318-325.
+ * Array in the reference's push order (depth-first pre-order, root = 0).
+ *   branch: a = children[0], b = children[1]           (b < RT_LEAF_BIT)
+ *   leaf:   a = shapes_range.start, b = count | RT_LEAF_BIT              */
+typedef struct RtNode {
+    float min[3];
+    uint32_t a;
+    float max[3];
+    uint32_t b;
+} RtNode;
+
+/* Sphere, /root/reference/src/shapes.rs:43-47. */
+typedef struct RtSphere {
+    float center[3];
+    float radius;
+    uint32_t material;
+} RtSphere;
+
+/* Plane, /root/reference/src/shapes.rs:119-123 (normal already normalised,
+ * /root/reference/src/config.rs:74). */
+typedef struct RtPlane {
+    float point[3];
+    float normal[3];
+    uint32_t material;
+} RtPlane;
+
+/* Triangle + NormalsTextureCoordinates, /root/reference/src/shapes.rs:185-193,
+ * 354-370.  Stored as vertex a and edges e1 = b-a, e2 = c-a (:203-205).
+ * An index equal to RT_NO_INDEX means that table is absent for the triangle;
+ * bary_idx is present iff normals_idx or uv_idx is.                        */
+typedef struct RtTriangle {
+    float a[3];
+    float e1[3];
+    float e2[3];
+    uint32_t normals_idx; /* into RtSceneDesc.vertex_normals   */
+    uint32_t uv_idx;      /* into RtSceneDesc.tex_coords       */
+    uint32_t bary_idx;    /* into RtSceneDesc.bary_precomputed */
+    uint32_t material;
+} RtTriangle;
+
+/* Material, /root/reference/src/material.rs:11-15.  For a texture,
+ * tex_offset is the byte offset of its first texel in RtSceneDesc.texels
+ * (packed RGB8, row-major, top row first, as read from a P6 file). */
+typedef struct RtMaterial {
+    uint32_t kind;       /* RtMaterialKind */
+    float param;         /* fuzziness / refractive index, else 0 */
+    uint32_t color_kind; /* RtColorKind */
+    float rgb[3];        /* solid colour */
+    uint32_t tex_width;
+    uint32_t tex_height;
+    uint64_t tex_offset;
+} RtMaterial;
+
+/* The immutable part of `Scene`, /root/reference/src/lib.rs:103-150:
+ * Shapes (three shape arrays + three per-triangle side tables), Bvhs (three
+ * node arrays) and the interned material table.  Shape arrays are in
+ * post-BVH-build order (the build permutes them in place,
+ * /root/reference/src/config.rs:113-134), so "primitive id" means the index
+ * into these arrays. */
+typedef struct RtSceneDesc {
+    const RtNode* sphere_nodes;
+    const RtNode* plane_nodes;
+    const RtNode* triangle_nodes;
+    const RtSphere* spheres;
+    const RtPlane* planes;
+    const RtTriangle* triangles;
+    const float* vertex_normals;   /* [n_vertex_normals][3][3] */
+    const float* tex_coords;       /* [n_tex_coords][3][2]     */
+    const float* bary_precomputed; /* [n_bary][4] = d00,d01,d11,denominator */
+    const RtMaterial* materials;
+    const uint8_t* texels;
+    uint64_t n_texel_bytes;
+    uint32_t n_sphere_nodes;
+    uint32_t n_plane_nodes;
+    uint32_t n_triangle_nodes;
+    uint32_t n_spheres;
+    uint32_t n_planes;
+    uint32_t n_triangles;
+    uint32_t n_vertex_normals;
+    uint32_t n_tex_coords;
+    uint32_t n_bary;
+    uint32_t n_materials;
+} RtSceneDesc;
+
+/* Screen + Camera + the two optional scene-file switches,
+ * /root/reference/src/lib.rs:103-107,378-418. */
+typedef struct RtRenderParams {
+    float top_left[3];
+    float top_edge[3];
+    float left_edge[3];
+    float camera[3];
+    uint32_t width;
+    uint32_t height;
+    uint32_t samples_per_pixel;
+    uint32_t max_bounces;
+    uint32_t incremental;       /* 0 = None, else samples per pass          */
+    uint32_t has_continue;      /* 0 = None                                  */
+    uint32_t continue_sampling; /* pass number to resume at (if has_continue) */
+    uint32_t rng_mode;          /* RtRngMode                                 */
+    uint64_t rng_seed;          /* RT_RNG_SEED reproduces the reference      */
+    /* Sub-rectangle of the image to work on; tile_w == 0 means the full
+     * image.  Pixel buffers passed with a tile are tile-sized, row-major. */
+    uint32_t tile_x;
+    uint32_t tile_y;
+    uint32_t tile_w;
+    uint32_t tile_h;
+} RtRenderParams;
+
+/* Result of a nearest-hit query for one ray. */
+typedef struct RtHitRecord {
+    float t;       /* +inf when nothing was hit */
+    uint32_t kind; /* RtShapeKind               */
+    uint32_t prim; /* index into that family's shape array, RT_NO_INDEX if none */
+} RtHitRecord;
+
+/* Work counters since creation or the last rt_reset_stats.
+ * A "segment" is one iteration of the bounce loop,
+ * /root/reference/src/lib.rs:313 — the unit of the Mrays/s metric.
+ * The three traversal counters are filled only while counting is enabled
+ * with rt_set_option(RT_OPT_COUNT_TRAVERSAL, 1) (slower kernels). */
+typedef struct RtStats {
+    uint64_t paths;          /* camera samples started                         */
+    uint64_t segments;       /* bounce-loop iterations                         */
+    uint64_t hits;           /* segments that hit a shape                      */
+    uint64_t branch_visits;  /* Branch nodes expanded (two box tests each)     */
+    uint64_t prim_tests[3];  /* sphere / plane / triangle intersection tests   */
+    uint64_t trace_launches; /* launches of the triangle traversal kernel      */
+    double trace_ms;         /* their summed duration (HIP events); needs
+                                rt_set_option(RT_OPT_TIME_KERNELS, 1)          */
+    double render_ms;        /* wall time inside rt_render / rt_render_sums    */
+} RtStats;
+
+typedef enum RtOption {
+    RT_OPT_COUNT_TRAVERSAL = 1, /* 0/1: fill branch_visits / prim_tests          */
+    RT_OPT_TIME_KERNELS = 2,    /* 0/1: bracket traversal launches with events   */
+    RT_OPT_SAMPLES_IN_FLIGHT = 3 /* samples per pixel traced concurrently (>=1)  */
+} RtOption;
+
+typedef struct RtContext RtContext;
+
+/* Called on the calling thread after each completed pass with the number of
+ * samples per pixel finished so far; stands in for the reference's
+ * `print!("\rSamples: {}")`, /root/reference/src/lib.rs:238-246. */
+typedef void (*RtProgressFn)(uint32_t samples_done, void* user);
+
+uint32_t rt_abi_version(void);
+
+/* Create a context on GPU `device_ordinal`.  Fails with RT_ERR_NO_DEVICE when
+ * there is none: there is no CPU fallback behind this library. */
+int rt_create(int device_ordinal, RtContext** out);
+void rt_destroy(RtContext* ctx);
+const char* rt_last_error(const RtContext* ctx);
+
+int rt_set_option(RtContext* ctx, uint32_t option, uint64_t value);
+
+/* Validate, re-lay-out and copy the scene to the GPU.  Replaces the hand-over
+ * of `&'static Scene` through `SCENE`, /root/reference/src/lib.rs:40. */
+int rt_upload_scene(RtContext* ctx, const RtSceneDesc* scene);
+
+/* Drop-in for `Scene::render`, /root/reference/src/lib.rs:188-301.
+ * `rgb8` is the pixel area of the output image (width*height*3 bytes, or the
+ * tile); it may be the mmap'd file itself.  It is read first when
+ * `incremental` or `continue` is set (the running average of :286-292 uses
+ * the stored bytes) and rewritten after every pass. */
+int rt_render(RtContext* ctx, const RtRenderParams* params, uint8_t* rgb8,
+              RtProgressFn progress, void* user);
+
+/* Linear radiance, summed (left fold in sample order, :274-279) over samples
+ * [sample_begin, sample_begin + sample_count) of every pixel of the tile:
+ * 3 floats per pixel.  `sums` is a host pointer, or a device pointer on this
+ * context's GPU when `sums_on_device` is non-zero.  This is the piece a
+ * multi-GPU driver partitions by sample range and reduces. */
+int rt_render_sums(RtContext* ctx, const RtRenderParams* params,
+                   uint32_t sample_begin, uint32_t sample_count, float* sums,
+                   int sums_on_device);
+
+/* Mean, gamma and quantisation of :283-295: rgb8 = u8(sqrt(sums/n)*255), or
+ * with `running_average` the blend with the bytes already in `rgb8` weighted
+ * by `sample_iteration`.  `sums` as in rt_render_sums; `rgb8` is host memory. */
+int rt_resolve(RtContext* ctx, const RtRenderParams* params, const float* sums,
+               int sums_on_device, uint32_t n_samples, int running_average,
+               uint32_t sample_iteration, uint8_t* rgb8);
+
+/* Nearest hit of the camera ray of sample `sample_index` for every pixel of
+ * the tile (one iteration of :313-333): the parity hook for primitive ids.
+ * With `jitter` zero the two sub-pixel offsets of :262-263 are taken as 0. */
+int rt_trace_primary(RtContext* ctx, const RtRenderParams* params,
+                     uint32_t sample_index, int jitter, RtHitRecord* out);
+
+/* Nearest hit for caller-supplied rays (origin[3], direction[3] per ray,
+ * host memory): `Scene::ray_color`'s three `closest_shape` calls plus the
+ * `min_by`, /root/reference/src/lib.rs:314-333. */
+int rt_trace_rays(RtContext* ctx, const float* origins, const float* directions,
+                  uint64_t n_rays, RtHitRecord* out);
+
+int rt_get_stats(RtContext* ctx, RtStats* out);
+int rt_reset_stats(RtContext* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_MI355_H */

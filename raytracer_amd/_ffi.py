@@ -1,0 +1,167 @@
+"""ctypes mirrors of include/rt_mi355.h and include/rt_host.h, and the loaders
+for the two in-tree shared libraries.
+
+The loaders fail loudly: there is no Python or CPU fallback for either library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+
+RT_ABI_VERSION = 1
+RT_LEAF_BIT = 0x80000000
+RT_NO_INDEX = 0xFFFFFFFF
+RT_RNG_SEED = 0x0EF6F79ED30BA75A
+
+RT_MAT_LAMBERTIAN, RT_MAT_METAL, RT_MAT_GLASS, RT_MAT_LIGHT = 0, 1, 2, 3
+RT_COLOR_SOLID, RT_COLOR_TEXTURE = 0, 1
+RT_SHAPE_SPHERE, RT_SHAPE_PLANE, RT_SHAPE_TRIANGLE, RT_SHAPE_NONE = 0, 1, 2, 3
+RT_RNG_SUBSTREAM, RT_RNG_SERIAL = 0, 1
+RT_OPT_COUNT_TRAVERSAL, RT_OPT_TIME_KERNELS, RT_OPT_SAMPLES_IN_FLIGHT = 1, 2, 3
+
+f32, u32, u64, u8 = C.c_float, C.c_uint32, C.c_uint64, C.c_uint8
+
+
+class RtNode(C.Structure):
+    _fields_ = [("min", f32 * 3), ("a", u32), ("max", f32 * 3), ("b", u32)]
+
+
+class RtSphere(C.Structure):
+    _fields_ = [("center", f32 * 3), ("radius", f32), ("material", u32)]
+
+
+class RtPlane(C.Structure):
+    _fields_ = [("point", f32 * 3), ("normal", f32 * 3), ("material", u32)]
+
+
+class RtTriangle(C.Structure):
+    _fields_ = [("a", f32 * 3), ("e1", f32 * 3), ("e2", f32 * 3), ("normals_idx", u32),
+                ("uv_idx", u32), ("bary_idx", u32), ("material", u32)]
+
+
+class RtMaterial(C.Structure):
+    _fields_ = [("kind", u32), ("param", f32), ("color_kind", u32), ("rgb", f32 * 3),
+                ("tex_width", u32), ("tex_height", u32), ("tex_offset", u64)]
+
+
+class RtSceneDesc(C.Structure):
+    _fields_ = [
+        ("sphere_nodes", C.POINTER(RtNode)), ("plane_nodes", C.POINTER(RtNode)),
+        ("triangle_nodes", C.POINTER(RtNode)), ("spheres", C.POINTER(RtSphere)),
+        ("planes", C.POINTER(RtPlane)), ("triangles", C.POINTER(RtTriangle)),
+        ("vertex_normals", C.POINTER(f32)), ("tex_coords", C.POINTER(f32)),
+        ("bary_precomputed", C.POINTER(f32)), ("materials", C.POINTER(RtMaterial)),
+        ("texels", C.POINTER(u8)), ("n_texel_bytes", u64),
+        ("n_sphere_nodes", u32), ("n_plane_nodes", u32), ("n_triangle_nodes", u32),
+        ("n_spheres", u32), ("n_planes", u32), ("n_triangles", u32),
+        ("n_vertex_normals", u32), ("n_tex_coords", u32), ("n_bary", u32), ("n_materials", u32),
+    ]
+
+
+class RtRenderParams(C.Structure):
+    _fields_ = [
+        ("top_left", f32 * 3), ("top_edge", f32 * 3), ("left_edge", f32 * 3), ("camera", f32 * 3),
+        ("width", u32), ("height", u32), ("samples_per_pixel", u32), ("max_bounces", u32),
+        ("incremental", u32), ("has_continue", u32), ("continue_sampling", u32), ("rng_mode", u32),
+        ("rng_seed", u64), ("tile_x", u32), ("tile_y", u32), ("tile_w", u32), ("tile_h", u32),
+    ]
+
+    def copy(self) -> "RtRenderParams":
+        out = RtRenderParams()
+        C.memmove(C.byref(out), C.byref(self), C.sizeof(RtRenderParams))
+        return out
+
+    def tile_shape(self) -> tuple[int, int]:
+        """(height, width) of the region pixel buffers cover."""
+        if self.tile_w:
+            return int(self.tile_h), int(self.tile_w)
+        return int(self.height), int(self.width)
+
+
+class RtHitRecord(C.Structure):
+    _fields_ = [("t", f32), ("kind", u32), ("prim", u32)]
+
+
+class RtStats(C.Structure):
+    _fields_ = [("paths", u64), ("segments", u64), ("hits", u64), ("branch_visits", u64),
+                ("prim_tests", u64 * 3), ("trace_launches", u64), ("trace_ms", C.c_double),
+                ("render_ms", C.c_double)]
+
+
+RtProgressFn = C.CFUNCTYPE(None, u32, C.c_void_p)
+
+_DEVICE_SYMBOLS = {
+    "rt_abi_version": (u32, []),
+    "rt_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "rt_destroy": (None, [C.c_void_p]),
+    "rt_last_error": (C.c_char_p, [C.c_void_p]),
+    "rt_set_option": (C.c_int, [C.c_void_p, u32, u64]),
+    "rt_upload_scene": (C.c_int, [C.c_void_p, C.POINTER(RtSceneDesc)]),
+    "rt_render": (C.c_int, [C.c_void_p, C.POINTER(RtRenderParams), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rt_render_sums": (C.c_int, [C.c_void_p, C.POINTER(RtRenderParams), u32, u32, C.c_void_p, C.c_int]),
+    "rt_resolve": (C.c_int, [C.c_void_p, C.POINTER(RtRenderParams), C.c_void_p, C.c_int, u32, C.c_int,
+                             u32, C.c_void_p]),
+    "rt_trace_primary": (C.c_int, [C.c_void_p, C.POINTER(RtRenderParams), u32, C.c_int, C.c_void_p]),
+    "rt_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u64, C.c_void_p]),
+    "rt_get_stats": (C.c_int, [C.c_void_p, C.POINTER(RtStats)]),
+    "rt_reset_stats": (C.c_int, [C.c_void_p]),
+}
+
+_HOST_SYMBOLS = {
+    "rth_parse_scene": (C.c_void_p, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
+    "rth_free_scene": (None, [C.c_void_p]),
+    "rth_scene_desc": (None, [C.c_void_p, C.POINTER(RtSceneDesc)]),
+    "rth_scene_params": (None, [C.c_void_p, C.POINTER(RtRenderParams)]),
+    "rth_build_bvh_spheres": (C.c_void_p, [C.c_void_p, u32, C.POINTER(u32)]),
+    "rth_build_bvh_planes": (C.c_void_p, [C.c_void_p, u32, C.POINTER(u32)]),
+    "rth_build_bvh_triangles": (C.c_void_p, [C.c_void_p, u32, C.POINTER(u32)]),
+    "rth_free": (None, [C.c_void_p]),
+    "rth_load_ppm_p6": (C.c_void_p, [C.c_char_p, C.POINTER(u32), C.POINTER(u32), C.c_char_p, C.c_size_t]),
+    "rth_image_open": (C.c_void_p, [C.c_char_p, u32, u32, C.c_char_p, C.c_size_t]),
+    "rth_image_pixels": (C.c_void_p, [C.c_void_p]),
+    "rth_image_header_len": (C.c_size_t, [C.c_void_p]),
+    "rth_image_flush": (None, [C.c_void_p]),
+    "rth_image_close": (None, [C.c_void_p]),
+}
+
+
+def _bind(lib: C.CDLL, table: dict) -> C.CDLL:
+    for name, (restype, argtypes) in table.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    return lib
+
+
+_host = None
+_device = None
+
+
+def host_lib() -> C.CDLL:
+    """librt_host.so (scene ingest).  Raises if it has not been built."""
+    global _host
+    if _host is None:
+        path = os.path.join(LIB_DIR, "librt_host.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `make -C raytracer_amd/csrc` "
+                               "(or __graft_entry__.build()) first")
+        _host = _bind(C.CDLL(path), _HOST_SYMBOLS)
+    return _host
+
+
+def device_lib() -> C.CDLL:
+    """librt_mi355.so (the HIP render loop).  Raises if it has not been built;
+    nothing in this package renders without it."""
+    global _device
+    if _device is None:
+        path = os.path.join(LIB_DIR, "librt_mi355.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `make -C raytracer_amd/csrc` "
+                               "(or __graft_entry__.build()) first; there is no CPU fallback")
+        _device = _bind(C.CDLL(path), _DEVICE_SYMBOLS)
+        if _device.rt_abi_version() != RT_ABI_VERSION:
+            raise RuntimeError("librt_mi355.so ABI version mismatch")
+    return _device

@@ -1,0 +1,82 @@
+// Memory-mapped binary PPM output image, the sink of
+// /root/reference/src/lib.rs:64-89 on top of /root/reference/src/mmap.rs:41-122.
+//
+// The file is opened read+write, created if missing and *never truncated*, then
+// sized to header + width*height*3 and mapped MAP_SHARED.  Whatever pixel bytes
+// a previous run left are therefore still there: that is the reference's
+// checkpoint for `continue(n)` and what makes the image viewable while it is
+// being rendered.  Only the header is rewritten on open.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cerrno>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "rt_host.h"
+
+struct RthImage {
+    uint8_t* base = nullptr;
+    size_t len = 0;
+    size_t header_len = 0;
+};
+
+static void set_err(char* err, size_t err_len, const std::string& msg) {
+    if (err && err_len) std::snprintf(err, err_len, "%s", msg.c_str());
+}
+
+extern "C" {
+
+RthImage* rth_image_open(const char* path, uint32_t width, uint32_t height, char* err,
+                         size_t err_len) {
+    char header[64];
+    const int header_len = std::snprintf(header, sizeof header, "P6\n%u %u 255\n", width, height);
+    const size_t len = static_cast<size_t>(header_len) + static_cast<size_t>(width) * height * 3;
+
+    const int fd = ::open(path, O_RDWR | O_CREAT, 0644);
+    if (fd < 0) {
+        set_err(err, err_len, std::string("open ") + path + ": " + std::strerror(errno));
+        return nullptr;
+    }
+    if (::ftruncate(fd, static_cast<off_t>(len)) != 0) {
+        set_err(err, err_len, std::string("set_len ") + path + ": " + std::strerror(errno));
+        ::close(fd);
+        return nullptr;
+    }
+    void* p = ::mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    ::close(fd);  // the mapping keeps the file alive, as in the reference
+    if (p == MAP_FAILED) {
+        set_err(err, err_len, std::string("mmap ") + path + ": " + std::strerror(errno));
+        return nullptr;
+    }
+    RthImage* img = new (std::nothrow) RthImage;
+    if (!img) {
+        ::munmap(p, len);
+        set_err(err, err_len, "out of memory");
+        return nullptr;
+    }
+    img->base = static_cast<uint8_t*>(p);
+    img->len = len;
+    img->header_len = static_cast<size_t>(header_len);
+    std::memcpy(img->base, header, img->header_len);
+    return img;
+}
+
+uint8_t* rth_image_pixels(RthImage* image) { return image ? image->base + image->header_len : nullptr; }
+
+size_t rth_image_header_len(const RthImage* image) { return image ? image->header_len : 0; }
+
+void rth_image_flush(RthImage* image) {
+    if (image) ::msync(image->base, image->len, MS_ASYNC);
+}
+
+void rth_image_close(RthImage* image) {
+    if (!image) return;
+    ::munmap(image->base, image->len);
+    delete image;
+}
+}
