@@ -1,0 +1,600 @@
+// HIP kernels of the render loop for gfx950 (wave64).
+//
+// One path = one camera sample.  A batch of paths moves through the bounce
+// loop of /root/reference/src/lib.rs:304-375 as a wavefront:
+//
+//   k_raygen                      camera rays + generator state      (once)
+//   per bounce:
+//     k_trace<SPHERE|PLANE|TRIANGLE>  nearest hit in that family's BVH
+//     k_shade                     sky / scatter / texture, compaction of the
+//                                 surviving paths into the next queue
+//   k_fold                        ordered per-pixel sum of the batch's samples
+//   k_quantize                    mean, gamma, running average, u8
+//
+// All arithmetic repeats the reference's operation order in IEEE binary32:
+// this file must be compiled with -ffp-contract=off (no fused multiply-add),
+// correctly rounded division and sqrt, and denormals preserved, so that every
+// value is bit-identical to the scalar CPU evaluation of the same formulas.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "layout.h"
+
+namespace rtd {
+
+// ------------------------------------------------------------------ vectors
+// Operation orders of /root/reference/src/vec3.rs.
+
+struct F3 {
+    float x, y, z;
+};
+__device__ __forceinline__ F3 f3(float x, float y, float z) { return F3{x, y, z}; }
+__device__ __forceinline__ F3 f3(const float* p) { return F3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ F3 f3(float4 v) { return F3{v.x, v.y, v.z}; }
+__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return F3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return F3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ F3 operator*(F3 a, F3 b) { return F3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ F3 operator*(F3 a, float s) { return F3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ F3 operator/(F3 a, float s) { return F3{a.x / s, a.y / s, a.z / s}; }
+__device__ __forceinline__ F3 operator-(F3 a) { return F3{-a.x, -a.y, -a.z}; }
+// vec3.rs:224-233
+__device__ __forceinline__ float dot(F3 a, F3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// vec3.rs:303-321
+__device__ __forceinline__ F3 cross(F3 a, F3 b) {
+    return F3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+// vec3.rs:285-291
+__device__ __forceinline__ F3 normalize(F3 a) { return a / sqrtf(dot(a, a)); }
+// vec3.rs:564-575
+__device__ __forceinline__ F3 reflect(F3 d, F3 n) { return d - (n * 2.0f) * dot(d, n); }
+
+// ---------------------------------------------------------------- generator
+// wyrand, /root/reference/src/rng.rs:19-41.
+
+constexpr unsigned long long kWy0 = 0x2d358dccaa6c78a5ull;
+constexpr unsigned long long kWy1 = 0x8bb84b93962eacc9ull;
+
+__device__ __forceinline__ float rng_f32(unsigned long long& s) {
+    s += kWy0;
+    const unsigned long long a = s, b = s ^ kWy1;
+    const unsigned long long lo = a * b, hi = __umul64hi(a, b);
+    const uint32_t u = static_cast<uint32_t>(lo ^ hi);
+    return __uint_as_float(0x3F800000u + (u >> 9)) - 1.0f;
+}
+
+// vec3.rs:549-558
+__device__ __forceinline__ F3 random_unit(unsigned long long& s) {
+    const float x = rng_f32(s) - 0.5f;
+    const float y = rng_f32(s) - 0.5f;
+    const float z = rng_f32(s) - 0.5f;
+    return normalize(f3(x, y, z));
+}
+
+// ------------------------------------------------------------ intersections
+
+constexpr float kMinDistance = 0.001f;        // shapes.rs:18
+constexpr float kEpsilon = 1.1920929e-7f;     // f32::EPSILON
+constexpr float kInfinity = __builtin_huge_valf();
+
+// bvh.rs:25-43
+__device__ __forceinline__ bool box_hit(const float* mn, const float* mx, F3 o, F3 d, float& tmin_out) {
+    const float t1x = (mn[0] - o.x) / d.x, t1y = (mn[1] - o.y) / d.y, t1z = (mn[2] - o.z) / d.z;
+    const float t2x = (mx[0] - o.x) / d.x, t2y = (mx[1] - o.y) / d.y, t2z = (mx[2] - o.z) / d.z;
+    const float tmin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
+    const float tmax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
+    tmin_out = tmin;
+    return tmax >= tmin && tmax > 0.0f;
+}
+
+// shapes.rs:60-87
+__device__ __forceinline__ bool sphere_hit(const DSphere& s, F3 o, F3 d, float& t) {
+    const F3 delta = o - f3(s.center);
+    const float b = dot(delta, d);
+    const float disc = b * b - dot(delta, delta) + s.radius * s.radius;
+    if (disc < 0.0f) return false;
+    const float root = sqrtf(disc);
+    const float t1 = -b - root;
+    if (t1 > kMinDistance) {
+        t = t1;
+        return true;
+    }
+    const float t2 = -b + root;
+    t = t2;
+    return t2 > kMinDistance;
+}
+
+// shapes.rs:141-154
+__device__ __forceinline__ bool plane_hit(const DPlane& p, F3 o, F3 d, float& t) {
+    const F3 n = f3(p.normal);
+    const float den = dot(n, d);
+    if (fabsf(den) < kEpsilon) return false;
+    const float num = dot(n, o - f3(p.point));
+    t = -(num / den);
+    return t > kMinDistance;
+}
+
+// shapes.rs:232-259
+__device__ __forceinline__ bool triangle_hit(F3 a, F3 e1, F3 e2, F3 o, F3 d, float& t) {
+    const F3 h = cross(d, e2);
+    const float det = dot(e1, h);
+    if (fabsf(det) < 2e-6f) return false;
+    const float inv = 1.0f / det;
+    const F3 s = o - a;
+    const float u = inv * dot(s, h);
+    if (!(u >= 0.0f && u <= 1.0f)) return false;
+    const F3 q = cross(s, e1);
+    const float v = inv * dot(d, q);
+    if (v < 0.0f || u + v > 1.0f) return false;
+    t = inv * dot(e2, q);
+    return t > kMinDistance;
+}
+
+// ------------------------------------------------------------------- trace
+
+// Persistent traversal kernel: one-wave workgroups; every lane owns one ray
+// and walks that ray's ordered stack exactly as bvh.rs:227-298 does.  Lanes
+// that finish fetch new rays from the queue through one wave-aggregated atomic
+// on the queue cursor, so a wave stays busy until the queue is drained.
+//
+// The stack's first kLdsSlots entries per lane live in LDS, laid out
+// [slot][lane] as 8-byte entries: lane l always touches banks 2l and 2l+1
+// (mod 64), whatever slot it is at, so divergent stack depths never conflict.
+// Deeper entries overflow to a private strip of global memory.
+
+constexpr int kTraceBlock = 64;
+constexpr int kLdsSlots = 16;
+constexpr uint32_t kRefillMin = 1;  // refill as soon as this many lanes are idle
+
+struct TraceArgs {
+    DFamily fam;
+    DQueue q;
+    const uint32_t* n_rays;  // device: rays in the queue
+    uint32_t* cursor;        // device: next unclaimed ray (zero before launch)
+    uint2* spill;            // [(slot - kLdsSlots)][grid threads]
+    uint32_t spill_stride;   // grid threads
+    unsigned long long* counters;  // [0] branch visits, [1] shape tests (COUNT only)
+};
+
+template <int KIND, bool COUNT>
+__global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
+    __shared__ uint2 s_stack[kLdsSlots][kTraceBlock];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t gtid = blockIdx.x * kTraceBlock + lane;
+    const uint32_t n = *a.n_rays;
+    const DNode* __restrict__ nodes = a.fam.nodes;
+
+    auto stack_store = [&](int slot, float dist, uint32_t ref) {
+        const uint2 e = make_uint2(__float_as_uint(dist), ref);
+        if (slot < kLdsSlots) s_stack[slot][lane] = e;
+        else a.spill[static_cast<size_t>(slot - kLdsSlots) * a.spill_stride + gtid] = e;
+    };
+    auto stack_load = [&](int slot) -> uint2 {
+        if (slot < kLdsSlots) return s_stack[slot][lane];
+        return a.spill[static_cast<size_t>(slot - kLdsSlots) * a.spill_stride + gtid];
+    };
+
+    bool active = false, exhausted = false;
+    uint32_t ray = 0, best_i = kHitNone;
+    int sp = 0;
+    F3 o = f3(0, 0, 0), d = f3(0, 0, 0);
+    float best_t = kInfinity;
+    unsigned long long n_branch = 0, n_tests = 0;
+
+    for (;;) {
+        if (!exhausted) {
+            const unsigned long long idle = __ballot(!active);
+            const uint32_t n_idle = __popcll(idle);
+            if (n_idle >= kRefillMin) {
+                const int leader = __ffsll(static_cast<long long>(idle)) - 1;
+                uint32_t base = 0;
+                if (static_cast<int>(lane) == leader) base = atomicAdd(a.cursor, n_idle);
+                base = __shfl(base, leader);
+                if (!active) {
+                    const uint32_t idx = base + __popcll(idle & ((1ull << lane) - 1ull));
+                    if (idx < n) {
+                        ray = idx;
+                        o = f3(a.q.origin[idx]);
+                        d = f3(a.q.direction[idx]);
+                        best_t = kInfinity;
+                        best_i = kHitNone;
+                        stack_store(0, 0.0f, a.fam.root_ref);  // bvh.rs:246, root box untested
+                        sp = 1;
+                        active = true;
+                    }
+                }
+                if (base + n_idle >= n) exhausted = true;
+            }
+        }
+        if (!__any(active)) break;
+
+        if (active) {
+            if (sp == 0) {
+                // bvh.rs:300 + lib.rs:333: keep the earlier family on equal distance.
+                if (best_t < a.q.hit_t[ray]) {
+                    a.q.hit_t[ray] = best_t;
+                    a.q.hit_id[ray] = (static_cast<uint32_t>(KIND) << kHitKindShift) | best_i;
+                }
+                active = false;
+            } else {
+                const uint2 e = stack_load(--sp);
+                const float entry_dist = __uint_as_float(e.x);
+                const uint32_t ref = e.y;
+                if (!(best_t <= entry_dist)) {
+                    if (!(ref & kLeafBit)) {
+                        const DNode& nd = nodes[ref];
+                        const float4 q0 = reinterpret_cast<const float4*>(&nd)[0];
+                        const float4 q1 = reinterpret_cast<const float4*>(&nd)[1];
+                        const float4 q2 = reinterpret_cast<const float4*>(&nd)[2];
+                        const uint4 q3 = reinterpret_cast<const uint4*>(&nd)[3];
+                        const float c0min[3] = {q0.x, q0.y, q0.z}, c0max[3] = {q0.w, q1.x, q1.y};
+                        const float c1min[3] = {q1.z, q1.w, q2.x}, c1max[3] = {q2.y, q2.z, q2.w};
+                        float d0, d1;
+                        bool h0 = box_hit(c0min, c0max, o, d, d0);
+                        bool h1 = box_hit(c1min, c1max, o, d, d1);
+                        h0 = h0 && d0 < best_t;  // bvh.rs:263-266
+                        h1 = h1 && d1 < best_t;
+                        if (COUNT) ++n_branch;
+                        if (h0 && h1) {
+                            // bvh.rs:268-277: far child first; on a tie child 1 ends on top
+                            const bool zero_near = d0 < d1;
+                            stack_store(sp, zero_near ? d1 : d0, zero_near ? q3.y : q3.x);
+                            stack_store(sp + 1, zero_near ? d0 : d1, zero_near ? q3.x : q3.y);
+                            sp += 2;
+                        } else if (h0) {
+                            stack_store(sp++, d0, q3.x);
+                        } else if (h1) {
+                            stack_store(sp++, d1, q3.y);
+                        }
+                    } else {
+                        uint32_t first = ref & kLeafFirstMask;
+                        uint32_t count = (ref >> kLeafCountShift) & 15u;
+                        if (count == kLeafLong) {
+                            const DLongLeaf ll = a.fam.long_leaves[first];
+                            first = ll.first;
+                            count = ll.count;
+                        }
+                        if (COUNT) n_tests += count;
+                        // bvh.rs:288-295: ascending index, strict `<`
+                        for (uint32_t i = first; i < first + count; ++i) {
+                            float t;
+                            bool hit;
+                            if (KIND == 0) {
+                                hit = sphere_hit(static_cast<const DSphere*>(a.fam.shapes)[i], o, d, t);
+                            } else if (KIND == 1) {
+                                hit = plane_hit(static_cast<const DPlane*>(a.fam.shapes)[i], o, d, t);
+                            } else {
+                                const float4* tp = reinterpret_cast<const float4*>(
+                                    static_cast<const DTriangle*>(a.fam.shapes) + i);
+                                const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+                                hit = triangle_hit(f3(v0.x, v0.y, v0.z), f3(v0.w, v1.x, v1.y),
+                                                   f3(v1.z, v1.w, v2.x), o, d, t);
+                            }
+                            if (hit && t < best_t) {
+                                best_t = t;
+                                best_i = i;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&a.counters[0], n_branch);
+        atomicAdd(&a.counters[1], n_tests);
+    }
+}
+
+// ------------------------------------------------------------------ raygen
+
+struct FrameArgs {
+    float top_left[3], row_step[3], column_step[3], camera[3];
+    uint32_t width, height;          // full image
+    uint32_t x0, y0, tile_w, tile_h; // region being rendered
+    unsigned long long seed;
+    unsigned long long stride;       // draws reserved per sample: 2 + 3*max_bounces
+};
+
+// lib.rs:261-268.  Path i of the batch is sample (first_sample + i / n_pixels)
+// of tile pixel (i % n_pixels); its generator starts at the sub-stream of
+// (sample, image pixel) and the two jitter draws come first, x then y.
+__global__ void k_raygen(FrameArgs f, DQueue q, uint32_t n_paths, uint32_t n_pixels,
+                         unsigned long long first_sample, int jitter, uint32_t* n_rays_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *n_rays_out = n_paths;
+    if (i >= n_paths) return;
+    const uint32_t j = i / n_pixels, pix = i - j * n_pixels;
+    const uint32_t x = f.x0 + pix % f.tile_w, y = f.y0 + pix / f.tile_w;
+    const unsigned long long sample = first_sample + j;
+    const unsigned long long k =
+        sample * static_cast<unsigned long long>(f.width) * f.height +
+        (static_cast<unsigned long long>(y) * f.width + x);
+    unsigned long long s = f.seed + k * f.stride * kWy0;
+    float jx = 0.0f, jy = 0.0f;
+    if (jitter) {
+        jx = rng_f32(s);
+        jy = rng_f32(s);
+    }
+    const F3 a = f3(f.row_step) * (static_cast<float>(x) + jx / 2.0f);
+    const F3 b = f3(f.column_step) * (static_cast<float>(y) + jy / 2.0f);
+    const F3 pixel = (f3(f.top_left) + a) + b;
+    const F3 cam = f3(f.camera);
+    const F3 dir = normalize(pixel - cam);
+    q.origin[i] = make_float4(cam.x, cam.y, cam.z, 0.0f);
+    q.direction[i] = make_float4(dir.x, dir.y, dir.z, 0.0f);
+    q.throughput[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    q.rng[i] = make_uint2(static_cast<uint32_t>(s), static_cast<uint32_t>(s >> 32));
+    q.slot[i] = i;
+    q.hit_t[i] = kInfinity;
+    q.hit_id[i] = kHitNone;
+}
+
+// Caller-supplied rays (rt_trace_rays).
+__global__ void k_load_rays(const float* origins, const float* directions, DQueue q, uint32_t n,
+                            uint32_t* n_rays_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *n_rays_out = n;
+    if (i >= n) return;
+    q.origin[i] = make_float4(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], 0.0f);
+    q.direction[i] = make_float4(directions[3 * i], directions[3 * i + 1], directions[3 * i + 2], 0.0f);
+    q.hit_t[i] = kInfinity;
+    q.hit_id[i] = kHitNone;
+}
+
+// ------------------------------------------------------------------- shade
+
+// material.rs:192-239
+__device__ __forceinline__ F3 color_sample(const DScene& sc, const DMaterial& m, float u_in, float v_in) {
+    if (m.color_kind == 0) return f3(m.rgb);
+    float c[2] = {u_in, v_in};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float fr = c[k] - truncf(c[k]);  // fract
+        float r = fmodf(fr, 1.0f);             // rem_euclid(1.)
+        if (r < 0.0f) r += 1.0f;
+        c[k] = r;
+    }
+    c[1] = 1.0f - c[1];
+    const uint32_t dim[2] = {m.tex_width, m.tex_height};
+    uint32_t i0[2], i1[2];
+    float de[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float e = c[k] * static_cast<float>(dim[k] - 1u);
+        const float e0f = floorf(e);
+        // `as usize` saturates; indices past the edge would be an out-of-bounds
+        // panic in the reference and are clamped here instead of faulting.
+        uint32_t e0 = !(e0f > 0.0f) ? 0u : (e0f >= static_cast<float>(dim[k] - 1u) ? dim[k] - 1u
+                                                                                   : static_cast<uint32_t>(e0f));
+        i0[k] = e0;
+        i1[k] = min(e0 + 1u, dim[k] - 1u);
+        de[k] = e - e0f;
+    }
+    const uint8_t* tex = sc.texels + m.tex_offset;
+    const size_t w = m.tex_width;
+    auto texel = [&](uint32_t x, uint32_t y) {
+        const uint8_t* t = tex + 3 * (x + y * w);
+        return f3(static_cast<float>(t[0]) / 255.0f, static_cast<float>(t[1]) / 255.0f,
+                  static_cast<float>(t[2]) / 255.0f);
+    };
+    const F3 c00 = texel(i0[0], i0[1]), c01 = texel(i0[0], i1[1]);
+    const F3 c10 = texel(i1[0], i0[1]), c11 = texel(i1[0], i1[1]);
+    const float dx = de[0], dy = de[1];
+    const F3 c0 = c00 * (1.0f - dx) + c10 * dx;  // vec3.rs:164-177
+    const F3 c1 = c01 * (1.0f - dx) + c11 * dx;
+    return c0 * (1.0f - dy) + c1 * dy;
+}
+
+struct ShadeArgs {
+    DScene scene;
+    DQueue cur, next;
+    const uint32_t* n_cur;
+    uint32_t* n_next;       // zero before launch
+    float4* result;         // [slot] final radiance of a finished path
+    unsigned long long* hits;  // segments that hit something
+    int last_bounce;        // this bounce is max_bounces-1
+};
+
+// One iteration of the bounce loop after the nearest hit is known,
+// lib.rs:335-371, with Material::scatter (material.rs:23-100) and the surface
+// attributes of shapes.rs:91-99,157-165,264-326 inlined.
+__global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
+    const uint32_t n = *a.n_cur;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t rounds = (n + stride - 1) / stride;
+    unsigned long long my_hits = 0;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t i = r * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        bool alive = false;  // continues into the next bounce
+        F3 no = f3(0, 0, 0), nd = f3(0, 0, 0), thr = f3(0, 0, 0);
+        unsigned long long rng = 0;
+        uint32_t slot = 0;
+        if (i < n) {
+            const F3 o = f3(a.cur.origin[i]), d = f3(a.cur.direction[i]);
+            thr = f3(a.cur.throughput[i]);
+            slot = a.cur.slot[i];
+            const uint32_t id = a.cur.hit_id[i];
+            if (id == kHitNone) {
+                // lib.rs:337-345
+                const float s = 0.5f * (d.y + 1.0f);
+                const F3 sky = f3(0.2f, 0.2f, 0.8f) * (1.0f - s) + f3(1.0f, 1.0f, 1.0f) * s;
+                thr = thr * sky;
+                a.result[slot] = make_float4(thr.x, thr.y, thr.z, 0.0f);
+            } else {
+                ++my_hits;
+                const uint2 rs = a.cur.rng[i];
+                rng = (static_cast<unsigned long long>(rs.y) << 32) | rs.x;
+                const float t = a.cur.hit_t[i];
+                const uint32_t kind = id >> kHitKindShift, prim = id & kHitPrimMask;
+                const F3 p = o + d * t;  // bvh.rs:303
+                F3 normal;
+                float uv0 = 0.0f, uv1 = 0.0f;
+                uint32_t mat_i;
+                if (kind == 0) {
+                    const DSphere s = static_cast<const DSphere*>(a.scene.family[0].shapes)[prim];
+                    normal = normalize(p - f3(s.center));
+                    mat_i = a.scene.sphere_material[prim];
+                } else if (kind == 1) {
+                    const DPlane pl = static_cast<const DPlane*>(a.scene.family[1].shapes)[prim];
+                    normal = f3(pl.normal);
+                    mat_i = a.scene.plane_material[prim];
+                } else {
+                    const float4* tp = reinterpret_cast<const float4*>(
+                        static_cast<const DTriangle*>(a.scene.family[2].shapes) + prim);
+                    const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+                    const F3 ta = f3(v0.x, v0.y, v0.z), e1 = f3(v0.w, v1.x, v1.y), e2 = f3(v1.z, v1.w, v2.x);
+                    const DTriAttr at = a.scene.tri_attr[prim];
+                    mat_i = at.material;
+                    if (at.bary_idx == 0xFFFFFFFFu) {
+                        normal = normalize(cross(e1, e2));
+                    } else {
+                        // shapes.rs:210-227
+                        const float4 pre = reinterpret_cast<const float4*>(a.scene.bary_precomputed)[at.bary_idx];
+                        const F3 ap = p - ta;
+                        const float d20 = dot(ap, e1), d21 = dot(ap, e2);
+                        const float bv = (pre.z * d20 - pre.y * d21) / pre.w;
+                        const float bw = (pre.x * d21 - pre.y * d20) / pre.w;
+                        const float bu = 1.0f - bv - bw;
+                        if (at.normals_idx != 0xFFFFFFFFu) {
+                            const float* nn = a.scene.vertex_normals + 9 * static_cast<size_t>(at.normals_idx);
+                            normal = normalize((f3(nn) * bu + f3(nn + 3) * bv) + f3(nn + 6) * bw);
+                        } else {
+                            normal = normalize(cross(e1, e2));
+                        }
+                        if (at.uv_idx != 0xFFFFFFFFu) {
+                            const float* c = a.scene.tex_coords + 6 * static_cast<size_t>(at.uv_idx);
+                            uv0 = (c[0] * bu + c[2] * bv) + c[4] * bw;
+                            uv1 = (c[1] * bu + c[3] * bv) + c[5] * bw;
+                        }
+                    }
+                }
+                const DMaterial m = a.scene.materials[mat_i];
+                no = p + normal * 1e-4f;  // material.rs:29
+                int what = 0;            // 0 scattered, 1 absorbed, 2 light
+                if (m.kind == 0) {
+                    const F3 dir = normalize(normal + random_unit(rng));
+                    const bool near_zero = fabsf(dir.x) < kEpsilon && fabsf(dir.y) < kEpsilon && fabsf(dir.z) < kEpsilon;
+                    nd = near_zero ? normal : dir;
+                } else if (m.kind == 1) {
+                    const F3 refl = reflect(d, normal);
+                    if (m.param == 0.0f) {
+                        nd = refl;
+                    } else {
+                        nd = normalize(refl + random_unit(rng) * m.param);
+                        if (!(dot(nd, normal) > 0.0f)) what = 1;
+                    }
+                } else if (m.kind == 2) {
+                    float eta;
+                    F3 nn;
+                    if (dot(d, normal) < 0.0f) {
+                        eta = 1.0f / m.param;
+                        nn = normal;
+                    } else {
+                        eta = m.param;
+                        nn = -normal;
+                    }
+                    const float cosv = fminf(dot(-d, nn), 1.0f);
+                    const float sinv = sqrtf(1.0f - cosv * cosv);
+                    float r0 = (1.0f - eta) / (1.0f + eta);
+                    r0 = r0 * r0;
+                    const float x = 1.0f - cosv;
+                    const float x5 = x * ((x * x) * (x * x));
+                    const float reflectance = r0 + (1.0f - r0) * x5;
+                    bool do_reflect = eta * sinv > 1.0f;
+                    if (!do_reflect) do_reflect = rng_f32(rng) < reflectance;  // draw only without total reflection
+                    if (do_reflect) {
+                        nd = reflect(d, nn);
+                    } else {
+                        const F3 perp = (d + nn * cosv) * eta;
+                        const float disc = 1.0f - eta * eta * (1.0f - cosv * cosv);
+                        nd = perp + nn * (-sqrtf(disc));
+                    }
+                } else {
+                    what = 2;
+                }
+                if (what == 1) {
+                    a.result[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // lib.rs:359-362
+                } else {
+                    thr = thr * color_sample(a.scene, m, uv0, uv1);
+                    if (what == 2 || a.last_bounce) {
+                        // a light ends the path; so does the bounce limit, which
+                        // returns the throughput reached so far (lib.rs:313,374)
+                        a.result[slot] = make_float4(thr.x, thr.y, thr.z, 0.0f);
+                    } else {
+                        alive = true;
+                    }
+                }
+            }
+        }
+        // compaction: one atomic per wave, survivors keep their relative order
+        const unsigned long long live = __ballot(alive);
+        if (live) {
+            const int leader = __ffsll(static_cast<long long>(live)) - 1;
+            uint32_t base = 0;
+            if (static_cast<int>(lane) == leader) base = atomicAdd(a.n_next, __popcll(live));
+            base = __shfl(base, leader);
+            if (alive) {
+                const uint32_t dst = base + __popcll(live & ((1ull << lane) - 1ull));
+                a.next.origin[dst] = make_float4(no.x, no.y, no.z, 0.0f);
+                a.next.direction[dst] = make_float4(nd.x, nd.y, nd.z, 0.0f);
+                a.next.throughput[dst] = make_float4(thr.x, thr.y, thr.z, 0.0f);
+                a.next.rng[dst] = make_uint2(static_cast<uint32_t>(rng), static_cast<uint32_t>(rng >> 32));
+                a.next.slot[dst] = slot;
+                a.next.hit_t[dst] = kInfinity;
+                a.next.hit_id[dst] = kHitNone;
+            }
+        }
+    }
+    // one atomic per wave for the hit counter
+    for (int off = 32; off > 0; off >>= 1) my_hits += __shfl_down(my_hits, off);
+    if (lane == 0 && my_hits) atomicAdd(a.hits, my_hits);
+}
+
+// ------------------------------------------------------------ accumulation
+
+// lib.rs:274-279: left fold of a pixel's samples in sample order.  `result`
+// holds the batch as [sample][pixel]; `first` says the running sum is empty.
+__global__ void k_fold(const float4* result, float* sums, uint32_t n_pixels, uint32_t n_samples, int first) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pixels) return;
+    float r, g, b;
+    uint32_t j = 0;
+    if (first) {
+        const float4 c = result[p];
+        r = c.x; g = c.y; b = c.z;
+        j = 1;
+    } else {
+        r = sums[3 * p]; g = sums[3 * p + 1]; b = sums[3 * p + 2];
+    }
+    for (; j < n_samples; ++j) {
+        const float4 c = result[static_cast<size_t>(j) * n_pixels + p];
+        r += c.x; g += c.y; b += c.z;
+    }
+    sums[3 * p] = r; sums[3 * p + 1] = g; sums[3 * p + 2] = b;
+}
+
+// `as u8` on f32 (convert.rs:53-55): toward zero, saturating, NaN to 0.
+__device__ __forceinline__ uint8_t to_u8(float v) {
+    if (!(v > 0.0f)) return 0;
+    if (v >= 255.0f) return 255;
+    return static_cast<uint8_t>(v);
+}
+
+// lib.rs:283-295 per channel.
+__global__ void k_quantize(const float* sums, uint8_t* rgb8, uint32_t n_values, uint32_t n_samples,
+                           int running_average, uint32_t sample_iteration) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_values) return;
+    const float mean = sums[i] / static_cast<float>(n_samples);
+    const float corrected = sqrtf(mean);
+    float v = corrected;
+    if (running_average) {
+        const float old = static_cast<float>(rgb8[i]) / 255.0f;
+        const float k = static_cast<float>(sample_iteration);
+        v = (old * k + corrected) / (k + 1.0f);
+    }
+    rgb8[i] = to_u8(v * 255.0f);
+}
+
+}  // namespace rtd

@@ -1,0 +1,119 @@
+// Device-side data layout of the scene and of the path queues in HBM.
+//
+// Scene (built once by rt_upload_scene, read-only afterwards)
+//   * BVH: one 64-byte record per *branch* node holding both children's boxes
+//     and both child references, so expanding a branch is one aligned 64-byte
+//     fetch (four 16-byte loads) instead of the parent plus two child records.
+//     The reference visits a branch by box-testing its two children
+//     (/root/reference/src/bvh.rs:259-267); this record is exactly the data
+//     that step reads.  Branch records keep the reference's depth-first order.
+//   * a child reference is 32 bits:
+//        bit 31 = 0: index of a branch record
+//        bit 31 = 1: leaf; bits 27..30 = shape count 0..14 and bits 0..26 the
+//                    first shape index, or count field 15 = "long leaf" with
+//                    bits 0..26 indexing a {first, count} table
+//     so a traversal stack entry is 8 bytes: entry distance + reference.
+//   * triangles: 48 bytes each (three 16-byte loads): a, e1, e2 and one
+//     padding dword — the operands of /root/reference/src/shapes.rs:232-259.
+//     Shading attributes live in separate arrays, untouched by traversal.
+//
+// Path queues (one record per live path, structure-of-arrays so that a wave
+// reading 64 consecutive paths issues full-width coalesced loads)
+//   origin float4 | direction float4 | throughput float4 | rng u64 | slot u32
+//   | hit distance f32 | hit id u32
+//   Two copies (current / next bounce); the shade kernel compacts survivors
+//   into the next one.
+#pragma once
+#include <cstdint>
+
+namespace rtd {
+
+constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kLeafCountShift = 27;
+constexpr uint32_t kLeafFirstMask = (1u << kLeafCountShift) - 1u;
+constexpr uint32_t kLeafLong = 15u;
+constexpr uint32_t kHitNone = 0xFFFFFFFFu;
+constexpr uint32_t kHitKindShift = 30;
+constexpr uint32_t kHitPrimMask = (1u << kHitKindShift) - 1u;
+
+struct alignas(16) DNode {
+    float c0min[3];
+    float c0max[3];
+    float c1min[3];
+    float c1max[3];
+    uint32_t ref0, ref1, pad0, pad1;
+};
+static_assert(sizeof(DNode) == 64, "branch record must be one 64-byte line");
+
+struct alignas(16) DTriangle {
+    float a[3];
+    float e1[3];
+    float e2[3];
+    float pad[3];
+};
+static_assert(sizeof(DTriangle) == 48, "triangle record is three 16-byte loads");
+
+struct alignas(16) DSphere {
+    float center[3];
+    float radius;
+};
+
+struct alignas(16) DPlane {
+    float point[3];
+    float pad0;
+    float normal[3];
+    float pad1;
+};
+
+struct DLongLeaf {
+    uint32_t first, count;
+};
+
+// Per-triangle shading attributes (NormalsTextureCoordinates + material).
+struct alignas(16) DTriAttr {
+    uint32_t normals_idx, uv_idx, bary_idx, material;
+};
+
+struct DMaterial {
+    uint32_t kind;
+    float param;
+    uint32_t color_kind;
+    float rgb[3];
+    uint32_t tex_width, tex_height;
+    uint64_t tex_offset;
+};
+
+// One shape family's acceleration structure on the device.
+struct DFamily {
+    const DNode* nodes;
+    const DLongLeaf* long_leaves;
+    const void* shapes;  // DSphere / DPlane / DTriangle
+    uint32_t root_ref;
+    uint32_t n_shapes;
+    uint32_t max_stack;  // deepest stack the traversal can need (tree depth + 1)
+};
+
+struct DScene {
+    DFamily family[3];
+    const uint32_t* sphere_material;
+    const uint32_t* plane_material;
+    const DTriAttr* tri_attr;
+    const float* vertex_normals;    // [n][3][3]
+    const float* tex_coords;        // [n][3][2]
+    const float* bary_precomputed;  // [n][4]
+    const DMaterial* materials;
+    const uint8_t* texels;
+};
+
+// One bounce's worth of live paths.
+struct DQueue {
+    float4* origin;
+    float4* direction;
+    float4* throughput;
+    uint2* rng;
+    uint32_t* slot;
+    float* hit_t;
+    uint32_t* hit_id;
+};
+
+}  // namespace rtd

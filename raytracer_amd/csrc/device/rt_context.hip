@@ -1,0 +1,837 @@
+// C ABI of librt_mi355.so (include/rt_mi355.h): context, scene upload with the
+// device re-layout, and the host-side driver of the wavefront bounce loop.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "layout.h"
+#include "rt_mi355.h"
+
+using namespace rtd;
+
+namespace {
+
+struct Family {
+    DNode* nodes = nullptr;
+    DLongLeaf* long_leaves = nullptr;
+    void* shapes = nullptr;
+    uint32_t root_ref = kLeafBit;  // empty leaf
+    uint32_t n_shapes = 0;
+    uint32_t max_stack = 1;
+};
+
+struct Workspace {
+    size_t cap_paths = 0;   // records per queue
+    size_t cap_pixels = 0;  // pixels of sums / rgb8
+    size_t cap_bounces = 0; // entries of the counter block
+    DQueue q[2] = {};
+    float4* result = nullptr;
+    float* sums = nullptr;
+    uint8_t* rgb8 = nullptr;
+    uint32_t* counters = nullptr;  // [0..B] queue lengths, then 3 cursors per bounce
+    uint2* spill = nullptr;
+    size_t spill_entries = 0;
+};
+
+}  // namespace
+
+struct RtContext {
+    int device = 0;
+    int n_cus = 0;
+    hipStream_t stream = nullptr;
+    std::string error;
+
+    bool has_scene = false;
+    Family fam[3];
+    uint32_t* sphere_material = nullptr;
+    uint32_t* plane_material = nullptr;
+    DTriAttr* tri_attr = nullptr;
+    float* vertex_normals = nullptr;
+    float* tex_coords = nullptr;
+    float* bary = nullptr;
+    DMaterial* materials = nullptr;
+    uint8_t* texels = nullptr;
+    uint32_t n_materials = 0;
+
+    Workspace ws;
+    unsigned long long* d_stats = nullptr;  // hits, then {branch visits, shape tests} per family
+    uint32_t* h_pinned = nullptr;           // small pinned read-back area
+    size_t h_pinned_words = 0;
+
+    uint32_t trace_grid = 0;
+    bool opt_count = false, opt_time = false;
+    uint64_t opt_samples_in_flight = 0;  // 0 = automatic
+    std::vector<hipEvent_t> events;      // pairs around timed launches
+    size_t events_used = 0;
+
+    RtStats stats{};
+};
+
+namespace {
+
+constexpr size_t kStatWords = 7;
+
+int fail(RtContext* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->error = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                   \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP,            \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+    } while (0)
+
+template <class T>
+int upload(RtContext* ctx, T** dst, const void* src, size_t count) {
+    *dst = nullptr;
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(dst), bytes));
+    if (count) HIP_TRY(ctx, hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+void free_scene(RtContext* ctx) {
+    for (Family& f : ctx->fam) {
+        (void)hipFree(f.nodes);
+        (void)hipFree(f.long_leaves);
+        (void)hipFree(f.shapes);
+        f = Family{};
+    }
+    (void)hipFree(ctx->sphere_material);
+    (void)hipFree(ctx->plane_material);
+    (void)hipFree(ctx->tri_attr);
+    (void)hipFree(ctx->vertex_normals);
+    (void)hipFree(ctx->tex_coords);
+    (void)hipFree(ctx->bary);
+    (void)hipFree(ctx->materials);
+    (void)hipFree(ctx->texels);
+    ctx->sphere_material = ctx->plane_material = nullptr;
+    ctx->tri_attr = nullptr;
+    ctx->vertex_normals = ctx->tex_coords = ctx->bary = nullptr;
+    ctx->materials = nullptr;
+    ctx->texels = nullptr;
+    ctx->has_scene = false;
+}
+
+void free_queue(DQueue& q) {
+    (void)hipFree(q.origin);
+    (void)hipFree(q.direction);
+    (void)hipFree(q.throughput);
+    (void)hipFree(q.rng);
+    (void)hipFree(q.slot);
+    (void)hipFree(q.hit_t);
+    (void)hipFree(q.hit_id);
+    q = DQueue{};
+}
+
+void free_workspace(RtContext* ctx) {
+    Workspace& w = ctx->ws;
+    free_queue(w.q[0]);
+    free_queue(w.q[1]);
+    (void)hipFree(w.result);
+    (void)hipFree(w.sums);
+    (void)hipFree(w.rgb8);
+    (void)hipFree(w.counters);
+    (void)hipFree(w.spill);
+    w = Workspace{};
+}
+
+// Re-lay-out one family's node array (reference order, 32-byte RtNode) into
+// branch records and child references; validates everything a kernel will
+// dereference so that a malformed description is refused here, not on the GPU.
+int build_family(RtContext* ctx, const char* name, const RtNode* nodes, uint32_t n_nodes, uint32_t n_shapes,
+                 Family& out, std::vector<DNode>& branches, std::vector<DLongLeaf>& long_leaves) {
+    branches.clear();
+    long_leaves.clear();
+    out.n_shapes = n_shapes;
+    out.root_ref = kLeafBit;
+    out.max_stack = 1;
+    if (n_nodes == 0) {
+        if (n_shapes != 0) return fail(ctx, RT_ERR_INVALID, std::string(name) + ": shapes without a BVH");
+        return RT_OK;
+    }
+    if (!nodes) return fail(ctx, RT_ERR_INVALID, std::string(name) + ": null node array");
+    if (n_shapes > kLeafFirstMask) return fail(ctx, RT_ERR_INVALID, std::string(name) + ": too many shapes");
+
+    std::vector<uint32_t> branch_id(n_nodes, 0xFFFFFFFFu), depth(n_nodes, 0);
+    uint32_t n_branch = 0;
+    for (uint32_t i = 0; i < n_nodes; ++i) {
+        const RtNode& nd = nodes[i];
+        if (nd.b & RT_LEAF_BIT) {
+            const uint64_t first = nd.a, count = nd.b & ~RT_LEAF_BIT;
+            if (first + count > n_shapes)
+                return fail(ctx, RT_ERR_INVALID, std::string(name) + ": leaf range outside the shape array");
+        } else {
+            // children are appended after their parent (bvh.rs:209-211); requiring
+            // that also rules out cycles
+            if (nd.a <= i || nd.b <= i || nd.a >= n_nodes || nd.b >= n_nodes)
+                return fail(ctx, RT_ERR_INVALID, std::string(name) + ": bad child index");
+            branch_id[i] = n_branch++;
+        }
+    }
+    auto ref_of = [&](uint32_t i) -> uint32_t {
+        const RtNode& nd = nodes[i];
+        if (!(nd.b & RT_LEAF_BIT)) return branch_id[i];
+        const uint32_t first = nd.a, count = nd.b & ~RT_LEAF_BIT;
+        if (count < kLeafLong) return kLeafBit | (count << kLeafCountShift) | first;
+        long_leaves.push_back(DLongLeaf{first, count});
+        return kLeafBit | (kLeafLong << kLeafCountShift) | static_cast<uint32_t>(long_leaves.size() - 1);
+    };
+    branches.resize(n_branch);
+    uint32_t max_depth = 0;
+    for (uint32_t i = 0; i < n_nodes; ++i) {
+        const RtNode& nd = nodes[i];
+        if (nd.b & RT_LEAF_BIT) continue;
+        const uint32_t c[2] = {nd.a, nd.b};
+        DNode& r = branches[branch_id[i]];
+        std::memcpy(r.c0min, nodes[c[0]].min, 12);
+        std::memcpy(r.c0max, nodes[c[0]].max, 12);
+        std::memcpy(r.c1min, nodes[c[1]].min, 12);
+        std::memcpy(r.c1max, nodes[c[1]].max, 12);
+        r.ref0 = ref_of(c[0]);
+        r.ref1 = ref_of(c[1]);
+        r.pad0 = r.pad1 = 0;
+        for (int k = 0; k < 2; ++k) {
+            depth[c[k]] = depth[i] + 1;
+            max_depth = std::max(max_depth, depth[c[k]]);
+        }
+    }
+    if (long_leaves.size() > kLeafFirstMask) return fail(ctx, RT_ERR_INVALID, std::string(name) + ": too many long leaves");
+    out.root_ref = ref_of(0);
+    out.max_stack = max_depth + 2;
+    return RT_OK;
+}
+
+int ensure_pinned(RtContext* ctx, size_t words) {
+    if (ctx->h_pinned_words >= words) return RT_OK;
+    if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    ctx->h_pinned = nullptr;
+    ctx->h_pinned_words = 0;
+    HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pinned), words * sizeof(uint32_t), hipHostMallocDefault));
+    ctx->h_pinned_words = words;
+    return RT_OK;
+}
+
+int alloc_queue(RtContext* ctx, DQueue& q, size_t n) {
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&q.origin), n * sizeof(float4)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&q.direction), n * sizeof(float4)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&q.throughput), n * sizeof(float4)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&q.rng), n * sizeof(uint2)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&q.slot), n * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&q.hit_t), n * sizeof(float)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&q.hit_id), n * sizeof(uint32_t)));
+    return RT_OK;
+}
+
+int ensure_workspace(RtContext* ctx, size_t n_paths, size_t n_pixels, size_t n_bounces) {
+    Workspace& w = ctx->ws;
+    if (w.cap_paths < n_paths) {
+        free_queue(w.q[0]);
+        free_queue(w.q[1]);
+        (void)hipFree(w.result);
+        w.result = nullptr;
+        w.cap_paths = 0;
+        int rc = alloc_queue(ctx, w.q[0], n_paths);
+        if (rc) return rc;
+        rc = alloc_queue(ctx, w.q[1], n_paths);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&w.result), n_paths * sizeof(float4)));
+        w.cap_paths = n_paths;
+    }
+    if (w.cap_pixels < n_pixels) {
+        (void)hipFree(w.sums);
+        (void)hipFree(w.rgb8);
+        w.sums = nullptr;
+        w.rgb8 = nullptr;
+        w.cap_pixels = 0;
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&w.sums), n_pixels * 3 * sizeof(float)));
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&w.rgb8), n_pixels * 3));
+        w.cap_pixels = n_pixels;
+    }
+    if (!w.counters || w.cap_bounces < n_bounces) {
+        (void)hipFree(w.counters);
+        w.counters = nullptr;
+        w.cap_bounces = 0;
+        // queue lengths [0..B], then 3 cursors for each of B bounces
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&w.counters), (n_bounces + 1 + 3 * n_bounces + 4) * sizeof(uint32_t)));
+        w.cap_bounces = n_bounces;
+    }
+    return ensure_pinned(ctx, n_bounces + 8);
+}
+
+struct Region {
+    uint32_t x0, y0, w, h;
+    size_t n_pixels;
+};
+
+int check_params(RtContext* ctx, const RtRenderParams* p, Region& r) {
+    if (!p) return fail(ctx, RT_ERR_INVALID, "null render parameters");
+    if (p->width < 2 || p->height < 2) return fail(ctx, RT_ERR_INVALID, "width and height must be at least 2");
+    if (p->rng_mode != RT_RNG_SUBSTREAM)
+        return fail(ctx, RT_ERR_INVALID, "the GPU implements RT_RNG_SUBSTREAM only");
+    if (p->tile_w) {
+        if (!p->tile_h || static_cast<uint64_t>(p->tile_x) + p->tile_w > p->width ||
+            static_cast<uint64_t>(p->tile_y) + p->tile_h > p->height)
+            return fail(ctx, RT_ERR_INVALID, "tile outside the image");
+        r = Region{p->tile_x, p->tile_y, p->tile_w, p->tile_h, static_cast<size_t>(p->tile_w) * p->tile_h};
+    } else {
+        r = Region{0, 0, p->width, p->height, static_cast<size_t>(p->width) * p->height};
+    }
+    if (r.n_pixels > 0x7FFFFFFFull) return fail(ctx, RT_ERR_INVALID, "region too large: render it in tiles");
+    return RT_OK;
+}
+
+FrameArgs frame_args(const RtRenderParams* p, const Region& r) {
+    FrameArgs f{};
+    // lib.rs:189-190, evaluated on the host in binary32 exactly as the kernels would
+    const float wm1 = static_cast<float>(p->width - 1), hm1 = static_cast<float>(p->height - 1);
+    for (int k = 0; k < 3; ++k) {
+        f.top_left[k] = p->top_left[k];
+        f.camera[k] = p->camera[k];
+        f.row_step[k] = p->top_edge[k] / wm1;
+        f.column_step[k] = p->left_edge[k] / hm1;
+    }
+    f.width = p->width;
+    f.height = p->height;
+    f.x0 = r.x0;
+    f.y0 = r.y0;
+    f.tile_w = r.w;
+    f.tile_h = r.h;
+    f.seed = p->rng_seed;
+    f.stride = 2ull + 3ull * p->max_bounces;
+    return f;
+}
+
+DScene device_scene(const RtContext* ctx) {
+    DScene s{};
+    for (int k = 0; k < 3; ++k) {
+        s.family[k].nodes = ctx->fam[k].nodes;
+        s.family[k].long_leaves = ctx->fam[k].long_leaves;
+        s.family[k].shapes = ctx->fam[k].shapes;
+        s.family[k].root_ref = ctx->fam[k].root_ref;
+        s.family[k].n_shapes = ctx->fam[k].n_shapes;
+        s.family[k].max_stack = ctx->fam[k].max_stack;
+    }
+    s.sphere_material = ctx->sphere_material;
+    s.plane_material = ctx->plane_material;
+    s.tri_attr = ctx->tri_attr;
+    s.vertex_normals = ctx->vertex_normals;
+    s.tex_coords = ctx->tex_coords;
+    s.bary_precomputed = ctx->bary;
+    s.materials = ctx->materials;
+    s.texels = ctx->texels;
+    return s;
+}
+
+template <int KIND>
+void launch_trace_kind(RtContext* ctx, const TraceArgs& a) {
+    if (ctx->opt_count)
+        hipLaunchKernelGGL((k_trace<KIND, true>), dim3(ctx->trace_grid), dim3(kTraceBlock), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL((k_trace<KIND, false>), dim3(ctx->trace_grid), dim3(kTraceBlock), 0, ctx->stream, a);
+}
+
+// Nearest hit of every ray in `q` over the three families, in the reference's
+// order (lib.rs:314-333).  `cursors` points at three zeroed words.
+int launch_trace(RtContext* ctx, const DQueue& q, const uint32_t* n_rays, uint32_t* cursors) {
+    const DScene sc = device_scene(ctx);
+    for (int kind = 0; kind < 3; ++kind) {
+        if (ctx->fam[kind].n_shapes == 0) continue;  // an empty family can never be hit
+        TraceArgs a{};
+        a.fam = sc.family[kind];
+        a.q = q;
+        a.n_rays = n_rays;
+        a.cursor = cursors + kind;
+        a.spill = ctx->ws.spill;
+        a.spill_stride = ctx->trace_grid * kTraceBlock;
+        a.counters = ctx->d_stats + 1 + 2 * kind;  // [branch visits, shape tests] of this family
+        const bool timed = ctx->opt_time && kind == RT_SHAPE_TRIANGLE;
+        if (timed) {
+            if (ctx->events_used + 2 > ctx->events.size()) {
+                for (int k = 0; k < 2; ++k) {
+                    hipEvent_t ev;
+                    HIP_TRY(ctx, hipEventCreate(&ev));
+                    ctx->events.push_back(ev);
+                }
+            }
+            HIP_TRY(ctx, hipEventRecord(ctx->events[ctx->events_used], ctx->stream));
+        }
+        if (kind == 0) launch_trace_kind<0>(ctx, a);
+        else if (kind == 1) launch_trace_kind<1>(ctx, a);
+        else launch_trace_kind<2>(ctx, a);
+        HIP_TRY(ctx, hipGetLastError());
+        if (timed) {
+            HIP_TRY(ctx, hipEventRecord(ctx->events[ctx->events_used + 1], ctx->stream));
+            ctx->events_used += 2;
+            ctx->stats.trace_launches++;
+        }
+    }
+    return RT_OK;
+}
+
+// After a stream synchronisation: fold event timings and device counters into
+// the host-side statistics.
+int harvest(RtContext* ctx) {
+    for (size_t i = 0; i + 1 < ctx->events_used; i += 2) {
+        float ms = 0.0f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->events[i], ctx->events[i + 1]));
+        ctx->stats.trace_ms += ms;
+    }
+    ctx->events_used = 0;
+    // d_stats: [0] hits, then [branch visits, shape tests] per family
+    unsigned long long h[kStatWords];
+    HIP_TRY(ctx, hipMemcpyAsync(h, ctx->d_stats, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stats.hits += h[0];
+    for (int kind = 0; kind < 3; ++kind) {
+        ctx->stats.branch_visits += h[1 + 2 * kind];
+        ctx->stats.prim_tests[kind] += h[2 + 2 * kind];
+    }
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof h, ctx->stream));
+    return RT_OK;
+}
+
+size_t choose_samples_in_flight(const RtContext* ctx, size_t n_pixels, uint32_t count) {
+    size_t s = ctx->opt_samples_in_flight;
+    if (s == 0) {
+        const size_t target_paths = size_t{1} << 23;  // enough to keep every CU busy through the tail
+        s = std::max<size_t>(1, target_paths / std::max<size_t>(n_pixels, 1));
+    }
+    s = std::min<size_t>(s, count);
+    // path indices and queue cursors are 32-bit
+    while (s > 1 && s * n_pixels > 0x7FFFFFFFull) --s;
+    return std::max<size_t>(s, 1);
+}
+
+// The bounce loop over samples [s_begin, s_begin + count) of the region into
+// the workspace's running sums (lib.rs:260-279 for every pixel).
+int render_sums_device(RtContext* ctx, const RtRenderParams* p, const Region& r, uint32_t s_begin, uint32_t count) {
+    if (count == 0) return fail(ctx, RT_ERR_INVALID, "sample_count must be at least 1");
+    const uint32_t B = p->max_bounces;
+    const size_t S = choose_samples_in_flight(ctx, r.n_pixels, count);
+    int rc = ensure_workspace(ctx, S * r.n_pixels, r.n_pixels, B);
+    if (rc) return rc;
+    Workspace& w = ctx->ws;
+    const FrameArgs f = frame_args(p, r);
+    const DScene sc = device_scene(ctx);
+    const uint32_t n_pix = static_cast<uint32_t>(r.n_pixels);
+    uint32_t* counts = w.counters;           // [0..B]
+    uint32_t* cursors = w.counters + B + 1;  // [B][3]
+    const size_t counter_words = B + 1 + 3 * static_cast<size_t>(B);
+    const int shade_grid = ctx->n_cus * 8;
+
+    for (uint32_t b0 = 0; b0 < count; b0 += static_cast<uint32_t>(S)) {
+        const uint32_t nb = std::min<uint32_t>(static_cast<uint32_t>(S), count - b0);
+        const uint32_t n_paths = nb * n_pix;
+        HIP_TRY(ctx, hipMemsetAsync(counts, 0, std::max<size_t>(counter_words, 1) * sizeof(uint32_t), ctx->stream));
+        if (B == 0) {
+            // lib.rs:313,374: no bounce, no colour -> black
+            HIP_TRY(ctx, hipMemsetAsync(w.result, 0, static_cast<size_t>(n_paths) * sizeof(float4), ctx->stream));
+        } else {
+            hipLaunchKernelGGL(k_raygen, dim3((n_paths + 255) / 256), dim3(256), 0, ctx->stream, f, w.q[0], n_paths,
+                               n_pix, static_cast<unsigned long long>(s_begin) + b0, 1, counts);
+            HIP_TRY(ctx, hipGetLastError());
+        }
+        ctx->stats.paths += n_paths;
+        for (uint32_t b = 0; b < B; ++b) {
+            const DQueue& cur = w.q[b & 1];
+            const DQueue& next = w.q[(b + 1) & 1];
+            rc = launch_trace(ctx, cur, counts + b, cursors + 3 * static_cast<size_t>(b));
+            if (rc) return rc;
+            ShadeArgs sa{};
+            sa.scene = sc;
+            sa.cur = cur;
+            sa.next = next;
+            sa.n_cur = counts + b;
+            sa.n_next = counts + b + 1;
+            sa.result = w.result;
+            sa.hits = ctx->d_stats;
+            sa.last_bounce = b + 1 == B;
+            hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(256), 0, ctx->stream, sa);
+            HIP_TRY(ctx, hipGetLastError());
+            // every few bounces look whether any path is still alive
+            if ((b & 3) == 3 && b + 1 < B) {
+                HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned, counts + b + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                if (ctx->h_pinned[0] == 0) break;
+            }
+        }
+        hipLaunchKernelGGL(k_fold, dim3((n_pix + 255) / 256), dim3(256), 0, ctx->stream, w.result, w.sums, n_pix, nb,
+                           b0 == 0 ? 1 : 0);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned, counts, (B + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        for (uint32_t b = 0; b < B; ++b) ctx->stats.segments += ctx->h_pinned[b];
+        rc = harvest(ctx);
+        if (rc) return rc;
+    }
+    return RT_OK;
+}
+
+int quantize_device(RtContext* ctx, const float* d_sums, size_t n_pixels, uint32_t n_samples, int running, uint32_t k) {
+    const uint32_t n_values = static_cast<uint32_t>(n_pixels * 3);
+    hipLaunchKernelGGL(k_quantize, dim3((n_values + 255) / 256), dim3(256), 0, ctx->stream, d_sums, ctx->ws.rgb8,
+                       n_values, n_samples, running, k);
+    HIP_TRY(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+struct Timer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+int require_scene(RtContext* ctx) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->has_scene) return fail(ctx, RT_ERR_STATE, "no scene uploaded");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return RT_OK;
+}
+
+// Hit queue entries -> RtHitRecord on the host.
+int download_hits(RtContext* ctx, const DQueue& q, size_t n, RtHitRecord* out) {
+    std::vector<float> t(n);
+    std::vector<uint32_t> id(n);
+    HIP_TRY(ctx, hipMemcpy(t.data(), q.hit_t, n * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(id.data(), q.hit_id, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) {
+        out[i].t = t[i];
+        if (id[i] == kHitNone) {
+            out[i].kind = RT_SHAPE_NONE;
+            out[i].prim = RT_NO_INDEX;
+        } else {
+            out[i].kind = id[i] >> kHitKindShift;
+            out[i].prim = id[i] & kHitPrimMask;
+        }
+    }
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t rt_abi_version(void) { return RT_ABI_VERSION; }
+
+int rt_create(int device_ordinal, RtContext** out) {
+    if (!out) return RT_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return RT_ERR_NO_DEVICE;
+    if (device_ordinal < 0 || device_ordinal >= n) return RT_ERR_NO_DEVICE;
+    RtContext* ctx = new (std::nothrow) RtContext;
+    if (!ctx) return RT_ERR_OOM;
+    ctx->device = device_ordinal;
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device_ordinal) != hipSuccess || hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&ctx->d_stats), kStatWords * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(ctx->d_stats, 0, kStatWords * sizeof(unsigned long long)) != hipSuccess) {
+        delete ctx;
+        return RT_ERR_HIP;
+    }
+    ctx->n_cus = prop.multiProcessorCount;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<2, false>, kTraceBlock, 0) != hipSuccess || per_cu < 1)
+        per_cu = 8;
+    ctx->trace_grid = static_cast<uint32_t>(ctx->n_cus) * static_cast<uint32_t>(per_cu);
+    *out = ctx;
+    return RT_OK;
+}
+
+void rt_destroy(RtContext* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_scene(ctx);
+    free_workspace(ctx);
+    for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
+    (void)hipFree(ctx->d_stats);
+    if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* rt_last_error(const RtContext* ctx) { return ctx ? ctx->error.c_str() : "null context"; }
+
+int rt_set_option(RtContext* ctx, uint32_t option, uint64_t value) {
+    if (!ctx) return RT_ERR_INVALID;
+    switch (option) {
+        case RT_OPT_COUNT_TRAVERSAL: ctx->opt_count = value != 0; return RT_OK;
+        case RT_OPT_TIME_KERNELS: ctx->opt_time = value != 0; return RT_OK;
+        case RT_OPT_SAMPLES_IN_FLIGHT: ctx->opt_samples_in_flight = value; return RT_OK;
+        default: return fail(ctx, RT_ERR_INVALID, "unknown option");
+    }
+}
+
+int rt_upload_scene(RtContext* ctx, const RtSceneDesc* s) {
+    if (!ctx || !s) return RT_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    free_scene(ctx);
+
+    // ---- validation of everything a kernel indexes with
+    if ((s->n_spheres && !s->spheres) || (s->n_planes && !s->planes) || (s->n_triangles && !s->triangles) ||
+        (s->n_materials && !s->materials) || (s->n_vertex_normals && !s->vertex_normals) ||
+        (s->n_tex_coords && !s->tex_coords) || (s->n_bary && !s->bary_precomputed) || (s->n_texel_bytes && !s->texels))
+        return fail(ctx, RT_ERR_INVALID, "null array with a non-zero count");
+    if (s->n_spheres > kHitPrimMask || s->n_planes > kHitPrimMask || s->n_triangles > kHitPrimMask)
+        return fail(ctx, RT_ERR_INVALID, "too many shapes");
+    for (uint32_t i = 0; i < s->n_spheres; ++i)
+        if (s->spheres[i].material >= s->n_materials) return fail(ctx, RT_ERR_INVALID, "sphere material index out of range");
+    for (uint32_t i = 0; i < s->n_planes; ++i)
+        if (s->planes[i].material >= s->n_materials) return fail(ctx, RT_ERR_INVALID, "plane material index out of range");
+    for (uint32_t i = 0; i < s->n_triangles; ++i) {
+        const RtTriangle& t = s->triangles[i];
+        if (t.material >= s->n_materials) return fail(ctx, RT_ERR_INVALID, "triangle material index out of range");
+        const bool any = t.normals_idx != RT_NO_INDEX || t.uv_idx != RT_NO_INDEX;
+        if ((t.normals_idx != RT_NO_INDEX && t.normals_idx >= s->n_vertex_normals) ||
+            (t.uv_idx != RT_NO_INDEX && t.uv_idx >= s->n_tex_coords) ||
+            (t.bary_idx != RT_NO_INDEX && t.bary_idx >= s->n_bary) || (any && t.bary_idx == RT_NO_INDEX))
+            return fail(ctx, RT_ERR_INVALID, "triangle side-table index out of range");
+    }
+    for (uint32_t i = 0; i < s->n_materials; ++i) {
+        const RtMaterial& m = s->materials[i];
+        if (m.kind > RT_MAT_LIGHT || m.color_kind > RT_COLOR_TEXTURE) return fail(ctx, RT_ERR_INVALID, "bad material kind");
+        if (m.color_kind == RT_COLOR_TEXTURE) {
+            const uint64_t bytes = static_cast<uint64_t>(m.tex_width) * m.tex_height * 3;
+            if (m.tex_width == 0 || m.tex_height == 0 || m.tex_offset > s->n_texel_bytes ||
+                bytes > s->n_texel_bytes - m.tex_offset)
+                return fail(ctx, RT_ERR_INVALID, "texture outside the texel array");
+        }
+    }
+
+    // ---- acceleration structures
+    const RtNode* node_arrays[3] = {s->sphere_nodes, s->plane_nodes, s->triangle_nodes};
+    const uint32_t node_counts[3] = {s->n_sphere_nodes, s->n_plane_nodes, s->n_triangle_nodes};
+    const uint32_t shape_counts[3] = {s->n_spheres, s->n_planes, s->n_triangles};
+    const char* names[3] = {"spheres", "planes", "triangles"};
+    uint32_t deepest = 1;
+    for (int k = 0; k < 3; ++k) {
+        std::vector<DNode> branches;
+        std::vector<DLongLeaf> longs;
+        int rc = build_family(ctx, names[k], node_arrays[k], node_counts[k], shape_counts[k], ctx->fam[k], branches, longs);
+        if (rc) { free_scene(ctx); return rc; }
+        rc = upload(ctx, &ctx->fam[k].nodes, branches.data(), branches.size());
+        if (!rc) rc = upload(ctx, &ctx->fam[k].long_leaves, longs.data(), longs.size());
+        if (rc) { free_scene(ctx); return rc; }
+        deepest = std::max(deepest, ctx->fam[k].max_stack);
+    }
+
+    // ---- shapes
+    {
+        std::vector<DSphere> sp(s->n_spheres);
+        std::vector<uint32_t> sm(s->n_spheres);
+        for (uint32_t i = 0; i < s->n_spheres; ++i) {
+            std::memcpy(sp[i].center, s->spheres[i].center, 12);
+            sp[i].radius = s->spheres[i].radius;
+            sm[i] = s->spheres[i].material;
+        }
+        std::vector<DPlane> pl(s->n_planes);
+        std::vector<uint32_t> pm(s->n_planes);
+        for (uint32_t i = 0; i < s->n_planes; ++i) {
+            std::memcpy(pl[i].point, s->planes[i].point, 12);
+            std::memcpy(pl[i].normal, s->planes[i].normal, 12);
+            pl[i].pad0 = pl[i].pad1 = 0.0f;
+            pm[i] = s->planes[i].material;
+        }
+        std::vector<DTriangle> tr(s->n_triangles);
+        std::vector<DTriAttr> ta(s->n_triangles);
+        for (uint32_t i = 0; i < s->n_triangles; ++i) {
+            const RtTriangle& t = s->triangles[i];
+            std::memcpy(tr[i].a, t.a, 12);
+            std::memcpy(tr[i].e1, t.e1, 12);
+            std::memcpy(tr[i].e2, t.e2, 12);
+            tr[i].pad[0] = tr[i].pad[1] = tr[i].pad[2] = 0.0f;
+            ta[i] = DTriAttr{t.normals_idx, t.uv_idx, t.bary_idx, t.material};
+        }
+        std::vector<DMaterial> mats(s->n_materials);
+        for (uint32_t i = 0; i < s->n_materials; ++i) {
+            const RtMaterial& m = s->materials[i];
+            mats[i] = DMaterial{m.kind, m.param, m.color_kind, {m.rgb[0], m.rgb[1], m.rgb[2]}, m.tex_width, m.tex_height, m.tex_offset};
+        }
+        DSphere* dsp = nullptr;
+        DPlane* dpl = nullptr;
+        DTriangle* dtr = nullptr;
+        int rc = upload(ctx, &dsp, sp.data(), sp.size());
+        ctx->fam[0].shapes = dsp;
+        if (!rc) { rc = upload(ctx, &dpl, pl.data(), pl.size()); ctx->fam[1].shapes = dpl; }
+        if (!rc) { rc = upload(ctx, &dtr, tr.data(), tr.size()); ctx->fam[2].shapes = dtr; }
+        if (!rc) rc = upload(ctx, &ctx->sphere_material, sm.data(), sm.size());
+        if (!rc) rc = upload(ctx, &ctx->plane_material, pm.data(), pm.size());
+        if (!rc) rc = upload(ctx, &ctx->tri_attr, ta.data(), ta.size());
+        if (!rc) rc = upload(ctx, &ctx->vertex_normals, s->vertex_normals, static_cast<size_t>(s->n_vertex_normals) * 9);
+        if (!rc) rc = upload(ctx, &ctx->tex_coords, s->tex_coords, static_cast<size_t>(s->n_tex_coords) * 6);
+        if (!rc) rc = upload(ctx, &ctx->bary, s->bary_precomputed, static_cast<size_t>(s->n_bary) * 4);
+        if (!rc) rc = upload(ctx, &ctx->materials, mats.data(), mats.size());
+        if (!rc) rc = upload(ctx, &ctx->texels, s->texels, static_cast<size_t>(s->n_texel_bytes));
+        if (rc) { free_scene(ctx); return rc; }
+        ctx->n_materials = s->n_materials;
+    }
+    HIP_TRY(ctx, hipDeviceSynchronize());  // uploads above went through the default stream
+
+    // ---- stack overflow area for trees deeper than the LDS part of the stack
+    {
+        Workspace& w = ctx->ws;
+        const size_t extra = deepest > static_cast<uint32_t>(kLdsSlots) ? deepest - kLdsSlots : 0;
+        const size_t entries = std::max<size_t>(1, extra * ctx->trace_grid * kTraceBlock);
+        if (w.spill_entries < entries) {
+            (void)hipFree(w.spill);
+            w.spill = nullptr;
+            w.spill_entries = 0;
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&w.spill), entries * sizeof(uint2)));
+            w.spill_entries = entries;
+        }
+    }
+    ctx->has_scene = true;
+    return RT_OK;
+}
+
+int rt_render_sums(RtContext* ctx, const RtRenderParams* p, uint32_t sample_begin, uint32_t sample_count, float* sums,
+                   int sums_on_device) {
+    int rc = require_scene(ctx);
+    if (rc) return rc;
+    Region r;
+    rc = check_params(ctx, p, r);
+    if (rc) return rc;
+    if (!sums) return fail(ctx, RT_ERR_INVALID, "null output");
+    Timer timer;
+    rc = render_sums_device(ctx, p, r, sample_begin, sample_count);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(sums, ctx->ws.sums, r.n_pixels * 3 * sizeof(float),
+                                sums_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stats.render_ms += timer.ms();
+    return RT_OK;
+}
+
+int rt_resolve(RtContext* ctx, const RtRenderParams* p, const float* sums, int sums_on_device, uint32_t n_samples,
+               int running_average, uint32_t sample_iteration, uint8_t* rgb8) {
+    if (!ctx) return RT_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Region r;
+    int rc = check_params(ctx, p, r);
+    if (rc) return rc;
+    if (!sums || !rgb8 || n_samples == 0) return fail(ctx, RT_ERR_INVALID, "bad resolve arguments");
+    rc = ensure_workspace(ctx, 0, r.n_pixels, 0);
+    if (rc) return rc;
+    Workspace& w = ctx->ws;
+    HIP_TRY(ctx, hipMemcpyAsync(w.sums, sums, r.n_pixels * 3 * sizeof(float),
+                                sums_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    if (running_average) HIP_TRY(ctx, hipMemcpyAsync(w.rgb8, rgb8, r.n_pixels * 3, hipMemcpyHostToDevice, ctx->stream));
+    rc = quantize_device(ctx, w.sums, r.n_pixels, n_samples, running_average, sample_iteration);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(rgb8, w.rgb8, r.n_pixels * 3, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_render(RtContext* ctx, const RtRenderParams* p, uint8_t* rgb8, RtProgressFn progress, void* user) {
+    int rc = require_scene(ctx);
+    if (rc) return rc;
+    Region r;
+    rc = check_params(ctx, p, r);
+    if (rc) return rc;
+    if (!rgb8) return fail(ctx, RT_ERR_INVALID, "null pixel buffer");
+    // lib.rs:206-211
+    const uint32_t chunk = p->incremental ? p->incremental : p->samples_per_pixel;
+    if (chunk == 0 || p->samples_per_pixel % chunk != 0)
+        return fail(ctx, RT_ERR_INVALID, "incremental must be non-zero and divide the samples per pixel");
+    const uint32_t n_passes = p->samples_per_pixel / chunk;
+    const int running = p->incremental != 0 || p->has_continue != 0;  // lib.rs:286
+    const uint32_t first_pass = p->has_continue ? p->continue_sampling : 0;
+    Timer timer;
+    rc = ensure_workspace(ctx, 0, r.n_pixels, 0);
+    if (rc) return rc;
+    if (running) HIP_TRY(ctx, hipMemcpyAsync(ctx->ws.rgb8, rgb8, r.n_pixels * 3, hipMemcpyHostToDevice, ctx->stream));
+    for (uint32_t pass = 0; pass < n_passes; ++pass) {
+        const uint32_t k = pass + first_pass;  // sample_iteration, lib.rs:233-234
+        const uint64_t s_begin = static_cast<uint64_t>(k) * chunk;
+        if (s_begin + chunk > 0xFFFFFFFFull) return fail(ctx, RT_ERR_INVALID, "sample index overflow");
+        rc = render_sums_device(ctx, p, r, static_cast<uint32_t>(s_begin), chunk);
+        if (rc) return rc;
+        rc = quantize_device(ctx, ctx->ws.sums, r.n_pixels, chunk, running, k);
+        if (rc) return rc;
+        // the image file is readable after every pass (live preview)
+        HIP_TRY(ctx, hipMemcpyAsync(rgb8, ctx->ws.rgb8, r.n_pixels * 3, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (progress) progress(first_pass + (pass + 1) * chunk, user);  // lib.rs:238-246
+    }
+    ctx->stats.render_ms += timer.ms();
+    return RT_OK;
+}
+
+int rt_trace_primary(RtContext* ctx, const RtRenderParams* p, uint32_t sample_index, int jitter, RtHitRecord* out) {
+    int rc = require_scene(ctx);
+    if (rc) return rc;
+    Region r;
+    rc = check_params(ctx, p, r);
+    if (rc) return rc;
+    if (!out) return fail(ctx, RT_ERR_INVALID, "null output");
+    rc = ensure_workspace(ctx, r.n_pixels, r.n_pixels, 1);
+    if (rc) return rc;
+    Workspace& w = ctx->ws;
+    const FrameArgs f = frame_args(p, r);
+    const uint32_t n = static_cast<uint32_t>(r.n_pixels);
+    HIP_TRY(ctx, hipMemsetAsync(w.counters, 0, 8 * sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(k_raygen, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, f, w.q[0], n, n,
+                       static_cast<unsigned long long>(sample_index), jitter ? 1 : 0, w.counters);
+    HIP_TRY(ctx, hipGetLastError());
+    rc = launch_trace(ctx, w.q[0], w.counters, w.counters + 2);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    rc = harvest(ctx);
+    if (rc) return rc;
+    return download_hits(ctx, w.q[0], n, out);
+}
+
+int rt_trace_rays(RtContext* ctx, const float* origins, const float* directions, uint64_t n_rays, RtHitRecord* out) {
+    int rc = require_scene(ctx);
+    if (rc) return rc;
+    if (n_rays == 0) return RT_OK;
+    if (!origins || !directions || !out) return fail(ctx, RT_ERR_INVALID, "null ray arrays");
+    if (n_rays > 0x7FFFFFFFull) return fail(ctx, RT_ERR_INVALID, "too many rays in one call");
+    rc = ensure_workspace(ctx, n_rays, 1, 1);
+    if (rc) return rc;
+    Workspace& w = ctx->ws;
+    const uint32_t n = static_cast<uint32_t>(n_rays);
+    // the second queue is unused here: stage the packed rays in two of its arrays
+    float* d_o = reinterpret_cast<float*>(w.q[1].origin);
+    float* d_d = reinterpret_cast<float*>(w.q[1].direction);
+    HIP_TRY(ctx, hipMemcpyAsync(d_o, origins, n_rays * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(d_d, directions, n_rays * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(w.counters, 0, 8 * sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(k_load_rays, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_o, d_d, w.q[0], n, w.counters);
+    HIP_TRY(ctx, hipGetLastError());
+    rc = launch_trace(ctx, w.q[0], w.counters, w.counters + 2);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    rc = harvest(ctx);
+    if (rc) return rc;
+    return download_hits(ctx, w.q[0], n, out);
+}
+
+int rt_get_stats(RtContext* ctx, RtStats* out) {
+    if (!ctx || !out) return RT_ERR_INVALID;
+    *out = ctx->stats;
+    return RT_OK;
+}
+
+int rt_reset_stats(RtContext* ctx) {
+    if (!ctx) return RT_ERR_INVALID;
+    ctx->stats = RtStats{};
+    return RT_OK;
+}
+
+}  // extern "C"

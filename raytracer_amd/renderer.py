@@ -1,0 +1,133 @@
+"""Thin Python wrapper over the C ABI of librt_mi355.so (include/rt_mi355.h).
+
+Every method is one call across the boundary; nothing is computed here.  There
+is no fallback: constructing a Renderer without the library or without a GPU
+raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi as F
+from .scene import HIT_DT, Scene
+
+
+class RtError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"librt_mi355 error {code}: {message}")
+        self.code = code
+
+
+class Renderer:
+    def __init__(self, device: int = 0):
+        self._lib = F.device_lib()
+        self._ctx = C.c_void_p()
+        rc = self._lib.rt_create(device, C.byref(self._ctx))
+        if rc != 0:
+            self._ctx = C.c_void_p()
+            raise RtError(rc, "rt_create failed (no usable GPU?)")
+        self._scene = None
+
+    # ---------------------------------------------------------------- plumbing
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            raise RtError(rc, self._lib.rt_last_error(self._ctx).decode())
+
+    def close(self) -> None:
+        if self._ctx:
+            self._lib.rt_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, option: int, value: int) -> None:
+        self._check(self._lib.rt_set_option(self._ctx, option, value))
+
+    # ------------------------------------------------------------------- scene
+    def upload(self, scene: Scene) -> None:
+        d = scene.desc()
+        self._check(self._lib.rt_upload_scene(self._ctx, C.byref(d)))
+        self._scene = scene
+
+    # ------------------------------------------------------------------ render
+    def render_into(self, params, pixels_ptr, progress=None) -> None:
+        """rt_render into caller memory (an address or ctypes pointer)."""
+        cb = F.RtProgressFn(lambda done, _user: progress(int(done))) if progress else None
+        self._check(self._lib.rt_render(self._ctx, C.byref(params), pixels_ptr,
+                                        C.cast(cb, C.c_void_p) if cb else None, None))
+
+    def render(self, params, rgb8: np.ndarray | None = None, progress=None) -> np.ndarray:
+        """`Scene::render` into a numpy image (read first if incremental/continue)."""
+        h, w = params.tile_shape()
+        if rgb8 is None:
+            rgb8 = np.zeros((h, w, 3), dtype=np.uint8)
+        assert rgb8.dtype == np.uint8 and rgb8.shape == (h, w, 3) and rgb8.flags.c_contiguous
+        self.render_into(params, rgb8.ctypes.data, progress)
+        return rgb8
+
+    def render_sums(self, params, sample_begin: int, sample_count: int) -> np.ndarray:
+        h, w = params.tile_shape()
+        out = np.empty((h, w, 3), dtype=np.float32)
+        self._check(self._lib.rt_render_sums(self._ctx, C.byref(params), sample_begin, sample_count,
+                                             out.ctypes.data, 0))
+        return out
+
+    def render_sums_device(self, params, sample_begin: int, sample_count: int, device_ptr: int) -> None:
+        """Same, into device memory on this context's GPU (3 floats per pixel)."""
+        self._check(self._lib.rt_render_sums(self._ctx, C.byref(params), sample_begin, sample_count,
+                                             C.c_void_p(device_ptr), 1))
+
+    def resolve(self, params, sums, n_samples: int, running_average: bool = False, sample_iteration: int = 0,
+                rgb8: np.ndarray | None = None, sums_on_device: bool = False) -> np.ndarray:
+        h, w = params.tile_shape()
+        if rgb8 is None:
+            rgb8 = np.zeros((h, w, 3), dtype=np.uint8)
+        if sums_on_device:
+            ptr = C.c_void_p(int(sums))
+        else:
+            sums = np.ascontiguousarray(sums, dtype=np.float32)
+            ptr = C.c_void_p(sums.ctypes.data)
+        self._check(self._lib.rt_resolve(self._ctx, C.byref(params), ptr, int(sums_on_device), n_samples,
+                                         int(running_average), sample_iteration, rgb8.ctypes.data))
+        return rgb8
+
+    # ------------------------------------------------------------------- trace
+    def trace_primary(self, params, sample_index: int = 0, jitter: bool = False) -> np.ndarray:
+        h, w = params.tile_shape()
+        out = np.zeros((h, w), dtype=HIT_DT)
+        self._check(self._lib.rt_trace_primary(self._ctx, C.byref(params), sample_index, int(jitter),
+                                               out.ctypes.data))
+        return out
+
+    def trace_rays(self, origins, directions) -> np.ndarray:
+        origins = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        directions = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        assert origins.shape == directions.shape
+        out = np.zeros(origins.shape[0], dtype=HIT_DT)
+        self._check(self._lib.rt_trace_rays(self._ctx, origins.ctypes.data, directions.ctypes.data,
+                                            origins.shape[0], out.ctypes.data))
+        return out
+
+    # ------------------------------------------------------------------- stats
+    def stats(self) -> dict:
+        s = F.RtStats()
+        self._check(self._lib.rt_get_stats(self._ctx, C.byref(s)))
+        return {"paths": int(s.paths), "segments": int(s.segments), "hits": int(s.hits),
+                "branch_visits": int(s.branch_visits), "prim_tests": [int(v) for v in s.prim_tests],
+                "trace_launches": int(s.trace_launches), "trace_ms": float(s.trace_ms),
+                "render_ms": float(s.render_ms)}
+
+    def reset_stats(self) -> None:
+        self._check(self._lib.rt_reset_stats(self._ctx))

@@ -1,0 +1,110 @@
+"""Small scenes shared by the tests (scene-file text, as the reference reads it)."""
+from __future__ import annotations
+
+import numpy as np
+
+from raytracer_amd import _ffi as F
+from raytracer_amd import assets, make_params, parse
+from raytracer_amd.scene import MATERIAL_DT, TRIANGLE_DT, Scene
+
+# the plumbing scene: red Lambertian sphere on a blue ground plane
+SPHERE_PLANE = """screen(-1.7778 2 1, 3.5556 0 0, 0 -2 0, {w}, {h}, {spp}, {bounces})
+camera(0 1 5)
+spheres((0 1 0, 1, lambertian, 1 0 0))
+planes((0 0 0, 0 1 0, lambertian, 0.1 0.1 0.6))
+triangles()
+"""
+
+# every material kind, all three shape families, scene-file triangles (no side tables)
+MATERIALS = """screen(-2 2.5 1, 4 0 0, 0 -2.5 0, {w}, {h}, {spp}, {bounces})
+camera(0 1.2 6)
+spheres((-1.5 0.5 0, 0.5, metal 0, 0.9 0.9 0.9), (-0.5 0.5 0.3, 0.5, metal 0.4, 0.8 0.6 0.2), (0.6 0.5 0.8, 0.5, glass 1.5, 1 1 1), (1.6 0.5 0, 0.5, lambertian, 0.2 0.8 0.3), (0 3.5 0, 1, light, 4 4 4), (0.6 0.5 0.8, 0.3, glass 1.5, 0.9 0.9 1))
+planes((0 0 0, 0 1 0, lambertian, 0.5 0.5 0.5), (0 0 -3, 0 0 1, metal 0.1, 0.7 0.7 0.9))
+triangles((-2 0 -1, 2 0 -1, 0 2.5 -1.5, lambertian, 0.9 0.3 0.3), (-2.5 0 1, -2.5 0 -2, -2.5 2 -0.5, light, 2 2 1))
+"""
+
+EMPTY = """screen(-1 1 1, 2 0 0, 0 -2 0, {w}, {h}, {spp}, {bounces})
+camera(0 0 3)
+spheres()
+planes()
+triangles()
+"""
+
+
+def sphere_plane(w=64, h=36, spp=4, bounces=10, prefix=""):
+    return parse(prefix + SPHERE_PLANE.format(w=w, h=h, spp=spp, bounces=bounces))
+
+
+def materials(w=64, h=40, spp=4, bounces=12, prefix=""):
+    return parse(prefix + MATERIALS.format(w=w, h=h, spp=spp, bounces=bounces))
+
+
+def empty(w=16, h=8, spp=2, bounces=4):
+    return parse(EMPTY.format(w=w, h=h, spp=spp, bounces=bounces))
+
+
+def room(asset_root, w=64, h=36, spp=4, bounces=12, incremental=None, cont=None):
+    return parse(assets.room_scene_text("room", w, h, spp, bounces, incremental, cont), asset_root)
+
+
+def blob(asset_root, w=48, h=48, spp=4, bounces=10):
+    return parse(assets.blob_scene_text("blob", w, h, spp, bounces), asset_root)
+
+
+def _triangles(tris, material=0):
+    out = np.zeros(len(tris), dtype=TRIANGLE_DT)
+    t = np.asarray(tris, dtype=np.float32).reshape(-1, 3, 3)
+    out["a"] = t[:, 0]
+    out["e1"] = t[:, 1] - t[:, 0]
+    out["e2"] = t[:, 2] - t[:, 0]
+    out["normals_idx"] = out["uv_idx"] = out["bary_idx"] = F.RT_NO_INDEX
+    out["material"] = material
+    return out
+
+
+def _one_material(kind=F.RT_MAT_LAMBERTIAN, rgb=(0.7, 0.7, 0.7), param=0.0):
+    m = np.zeros(1, dtype=MATERIAL_DT)
+    m["kind"], m["param"], m["color_kind"], m["rgb"] = kind, param, F.RT_COLOR_SOLID, rgb
+    return m
+
+
+def camera_params(w=32, h=32, spp=2, bounces=6, z=5.0):
+    return make_params((-1, 1, z - 1), (2, 0, 0), (0, -2, 0), (0, 0, z), w, h, spp, bounces)
+
+
+def deep_chain(n=60, **kw) -> Scene:
+    """Triangles at exponentially growing x: the surface-area heuristic peels
+    them off one at a time, giving a BVH about n levels deep (deeper than the
+    part of the traversal stack kept in LDS)."""
+    tris = []
+    for k in range(n):
+        x = 4.0 ** k * 1e-18  # surface areas stay inside the binary32 range
+        s = x * 0.2
+        tris.append([[x, -s, -3.0], [x + s, s, -3.0], [x - s, s, -3.0]])
+    p = camera_params(**kw)
+    return Scene.from_shapes(p, triangles=_triangles(tris), materials=_one_material())
+
+
+def stacked_duplicates(n=40, **kw) -> Scene:
+    """n coincident triangles: all centroids equal, so no split separates them
+    and the BVH is one leaf of n shapes (more than a child reference can count
+    inline); every ray through them hits all n at the same distance."""
+    tris = [[[-3.2, -3.2, 0.0], [3.2, -3.2, 0.0], [0.0, 3.6, 0.0]]] * n
+    p = camera_params(**kw)
+    return Scene.from_shapes(p, triangles=_triangles(tris), materials=_one_material())
+
+
+def grid_wall(n=16, **kw) -> Scene:
+    """A tessellated wall facing the camera: rays through shared edges and
+    vertices exercise the equal-distance tie rules."""
+    v, f, _ = assets.grid_patch((-4, -4, 0), (8, 0, 0), (0, 8, 0), n, n)
+    p = camera_params(**kw)
+    return Scene.from_shapes(p, triangles=_triangles(v[f]), materials=_one_material())
+
+
+def bvh_depth(nodes) -> int:
+    depth = np.zeros(len(nodes), dtype=np.int64)
+    for i, nd in enumerate(nodes):
+        if not (int(nd["b"]) & F.RT_LEAF_BIT):
+            depth[int(nd["a"])] = depth[int(nd["b"])] = depth[i] + 1
+    return int(depth.max()) if len(nodes) else 0

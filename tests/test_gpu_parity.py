@@ -1,0 +1,226 @@
+"""GPU parity: every result of librt_mi355.so, reached through its C ABI, is
+compared bit for bit with the CPU oracle on the same inputs.
+
+The bar is exact equality — hit distances, primitive ids, per-pixel radiance
+sums (float bit patterns) and stored bytes — because the kernels repeat the
+oracle's IEEE binary32 operation order (no FMA, true division) and samples of a
+pixel are folded in sample order.
+"""
+import numpy as np
+import pytest
+
+from oracle import binding as O
+from raytracer_amd import _ffi as F
+
+from . import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_hits_equal(gpu, cpu):
+    assert np.array_equal(gpu["kind"], cpu["kind"]), "shape family differs"
+    assert np.array_equal(gpu["prim"], cpu["prim"]), "primitive id differs"
+    assert np.array_equal(bits(gpu["t"]), bits(cpu["t"])), "hit distance differs"
+
+
+def check_scene(renderer, scene, spp=None, traversal_counters=True):
+    p = scene.params
+    spp = spp or p.samples_per_pixel
+    renderer.upload(scene)
+    # primary hits, with and without jitter
+    for jitter in (False, True):
+        assert_hits_equal(renderer.trace_primary(p, 1, jitter), O.trace_primary(scene, p, 1, jitter))
+    # radiance sums: exact, and the same work counted
+    renderer.set_option(F.RT_OPT_COUNT_TRAVERSAL, 1 if traversal_counters else 0)
+    renderer.reset_stats()
+    c = O.OracleCounters()
+    cpu = O.render_sums(scene, p, 0, spp, threads=4, counters=c)
+    gpu = renderer.render_sums(p, 0, spp)
+    renderer.set_option(F.RT_OPT_COUNT_TRAVERSAL, 0)
+    assert np.array_equal(bits(gpu), bits(cpu)), f"radiance differs in {np.count_nonzero(bits(gpu) != bits(cpu))} values"
+    s = renderer.stats()
+    assert s["paths"] == c.paths and s["segments"] == c.segments and s["hits"] == c.hits
+    if traversal_counters:
+        assert s["branch_visits"] == c.branch_visits
+        assert s["prim_tests"] == list(c.prim_tests)
+    # stored image
+    cpu_img, _ = O.render(scene, p, threads=4)
+    gpu_img = renderer.render(p)
+    assert np.array_equal(gpu_img, cpu_img)
+    return gpu
+
+
+def test_sphere_plane(renderer):
+    check_scene(renderer, scenes.sphere_plane(w=64, h=36, spp=4))
+
+
+def test_all_materials(renderer):
+    check_scene(renderer, scenes.materials(w=80, h=50, spp=6, bounces=12))
+
+
+def test_mesh_with_vertex_normals(renderer, asset_root):
+    check_scene(renderer, scenes.blob(asset_root, w=48, h=48, spp=3))
+
+
+def test_textured_room(renderer, asset_root):
+    check_scene(renderer, scenes.room(asset_root, w=64, h=36, spp=3, bounces=20))
+
+
+def test_empty_scene_is_sky(renderer):
+    s = scenes.empty()
+    gpu = check_scene(renderer, s)
+    assert np.all(gpu > 0)
+
+
+def test_zero_bounces_is_black(renderer):
+    s = scenes.sphere_plane(w=16, h=8, spp=2, bounces=0)
+    gpu = check_scene(renderer, s, traversal_counters=False)
+    assert np.all(gpu == 0)
+
+
+def test_one_bounce_returns_throughput(renderer):
+    # bounce-limit exhaustion keeps the accumulated colour (not black)
+    gpu = check_scene(renderer, scenes.sphere_plane(w=32, h=18, spp=2, bounces=1))
+    assert gpu.max() > 0
+
+
+def test_deep_tree_spills_past_lds_stack(renderer):
+    s = scenes.deep_chain(n=60, w=48, h=16)
+    assert scenes.bvh_depth(s.triangle_nodes) > 20
+    check_scene(renderer, s)
+    # rays along the chain visit many levels
+    o = np.tile(np.array([[-1.0, 0.0, -3.0]], np.float32), (64, 1))
+    d = np.tile(np.array([[1.0, 0.0, 0.0]], np.float32), (64, 1))
+    d[:, 1] = np.linspace(-0.1, 0.1, 64)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    assert_hits_equal(renderer.trace_rays(o, d), O.trace_rays(s, o, d))
+
+
+def test_long_leaf_and_equal_distance_ties(renderer):
+    s = scenes.stacked_duplicates(n=40, w=24, h=24)
+    assert len(s.triangle_nodes) == 1
+    check_scene(renderer, s)
+    hits = renderer.trace_primary(s.params, 0, False)
+    hit = hits["kind"] == F.RT_SHAPE_TRIANGLE
+    assert hit.any() and np.all(hits["prim"][hit] == 0)  # lowest index wins an exact tie
+
+
+def test_shared_edges_and_axis_aligned_rays(renderer):
+    s = scenes.grid_wall(n=16, w=33, h=33)
+    check_scene(renderer, s)
+    # rays aimed exactly at grid vertices and edge midpoints, axis-aligned directions
+    # (zero direction components give +-inf and NaN in the slab test)
+    g = np.linspace(-4, 4, 33, dtype=np.float32)
+    xx, yy = np.meshgrid(g, g)
+    o = np.stack([xx.ravel(), yy.ravel(), np.full(xx.size, 4.0, np.float32)], -1)
+    d = np.tile(np.array([[0.0, 0.0, -1.0]], np.float32), (o.shape[0], 1))
+    assert_hits_equal(renderer.trace_rays(o, d), O.trace_rays(s, o, d))
+    # rays lying in the wall's plane and rays starting on it
+    o2 = np.stack([np.full(33, -6.0, np.float32), g, np.zeros(33, np.float32)], -1)
+    d2 = np.tile(np.array([[1.0, 0.0, 0.0]], np.float32), (33, 1))
+    assert_hits_equal(renderer.trace_rays(o2, d2), O.trace_rays(s, o2, d2))
+
+
+def test_random_rays_against_room(renderer, asset_root):
+    s = scenes.room(asset_root)
+    renderer.upload(s)
+    rng = np.random.default_rng(3)
+    n = 20000
+    o = rng.uniform([-2.9, 0.1, -3.9], [2.9, 3.1, 4.9], size=(n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[::7, 0] = 0.0  # some with exact zeros
+    d[::11, 1] = 0.0
+    assert_hits_equal(renderer.trace_rays(o, d), O.trace_rays(s, o, d))
+
+
+def test_tile_equals_crop_of_full_frame(renderer):
+    s = scenes.materials(w=40, h=30, spp=3)
+    renderer.upload(s)
+    full = renderer.render_sums(s.params, 0, 3)
+    p = s.params.copy()
+    p.tile_x, p.tile_y, p.tile_w, p.tile_h = 7, 5, 13, 11
+    tile = renderer.render_sums(p, 0, 3)
+    assert np.array_equal(bits(tile), bits(full[5:16, 7:20]))
+    assert np.array_equal(bits(tile), bits(O.render_sums(s, p, 0, 3)))
+
+
+def test_samples_in_flight_do_not_change_results(renderer, asset_root):
+    s = scenes.room(asset_root, w=32, h=18, spp=5, bounces=10)
+    renderer.upload(s)
+    ref = None
+    for in_flight in (1, 2, 5, 0):
+        renderer.set_option(F.RT_OPT_SAMPLES_IN_FLIGHT, in_flight)
+        got = renderer.render_sums(s.params, 2, 5)
+        if ref is None:
+            ref = got
+        assert np.array_equal(bits(got), bits(ref))
+    assert np.array_equal(bits(ref), bits(O.render_sums(s, s.params, 2, 5)))
+
+
+def test_sample_ranges_are_independent_substreams(renderer):
+    # sums over [0,6) == fold of [0,2) then [2,6) only up to rounding order, but each range
+    # matches the oracle exactly and depends on nothing else
+    s = scenes.sphere_plane(w=32, h=18, spp=6)
+    renderer.upload(s)
+    for begin, count in ((0, 2), (2, 4), (1000000, 3)):
+        assert np.array_equal(bits(renderer.render_sums(s.params, begin, count)),
+                              bits(O.render_sums(s, s.params, begin, count)))
+
+
+def test_incremental_and_continue(renderer):
+    # incremental(2): three passes of 2 samples, running average of stored bytes
+    s = scenes.materials(w=40, h=24, spp=6, prefix="incremental(2)\n")
+    renderer.upload(s)
+    passes = []
+    gpu = renderer.render(s.params, progress=passes.append)
+    cpu, _ = O.render(s, s.params, threads=2)
+    assert np.array_equal(gpu, cpu)
+    assert passes == [2, 4, 6]
+    # continue(3) resumes from the stored bytes with fresh sub-streams
+    s2 = scenes.materials(w=40, h=24, spp=4, prefix="continue(3)\nincremental(2)\n")
+    gpu2 = renderer.render(s2.params, rgb8=gpu.copy())
+    cpu2, _ = O.render(s2, s2.params, rgb8=cpu.copy(), threads=2)
+    assert np.array_equal(gpu2, cpu2)
+    assert not np.array_equal(gpu2, gpu)
+
+
+def test_resolve_matches_oracle(renderer):
+    s = scenes.sphere_plane(w=32, h=18, spp=4)
+    renderer.upload(s)
+    sums = renderer.render_sums(s.params, 0, 4)
+    # include values outside [0,1], NaN and infinities: the cast saturates, NaN -> 0
+    sums[0, 0] = [np.nan, np.inf, -1.0]
+    sums[0, 1] = [1e30, 4.0, 3.9999]
+    assert np.array_equal(renderer.resolve(s.params, sums, 4), O.resolve(s.params, sums, 4))
+    old = np.random.default_rng(1).integers(0, 256, size=(18, 32, 3), dtype=np.uint8)
+    assert np.array_equal(renderer.resolve(s.params, sums, 4, True, 7, old.copy()),
+                          O.resolve(s.params, sums, 4, True, 7, old.copy()))
+
+
+def test_errors_are_reported_not_fatal(renderer):
+    from raytracer_amd.renderer import Renderer, RtError
+
+    s = scenes.sphere_plane(w=16, h=8, spp=1)
+    with Renderer(0) as r:
+        with pytest.raises(RtError) as e:
+            r.render_sums(s.params, 0, 1)  # nothing uploaded yet
+        assert e.value.code == -5
+        bad = scenes.sphere_plane(w=16, h=8, spp=1)
+        bad.spheres["material"] = 99
+        with pytest.raises(RtError) as e:
+            r.upload(bad)
+        assert e.value.code == -1
+        r.upload(s)
+        p = s.params.copy()
+        p.rng_mode = F.RT_RNG_SERIAL
+        with pytest.raises(RtError):
+            r.render_sums(p, 0, 1)
+        p = s.params.copy()
+        p.tile_x, p.tile_w, p.tile_h = 10, 10, 4
+        with pytest.raises(RtError):
+            r.render_sums(p, 0, 1)
