@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s (all bounces) on the breakfast-room-class scene
+at 1920x1080, 256 samples per pixel, 60 bounces.
+
+  python bench.py --gpus N --steps K --warmup W
+
+A step is one complete render of the frame: every rank renders its share of the
+256 samples of every pixel (rt_render_sums into a device buffer), the radiance
+buffers are summed onto rank 0 (RCCL reduce; nothing at N=1) and rank 0 applies
+mean/gamma/quantisation and reads the bytes back (rt_resolve).  Scene parsing
+and BVH construction happen once before the timed region; the scene is
+resident in HBM when timing starts.  A "ray" is one iteration of the bounce
+loop (/root/reference/src/lib.rs:313).  The breakfast_room mesh itself is not
+in the reference checkout, so the scene is the generated stand-in of
+raytracer_amd.assets.write_room (same camera as scenes/breakfast-room).
+
+Rank 0 prints one JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from raytracer_amd import _ffi as F  # noqa: E402
+from raytracer_amd import assets, parse  # noqa: E402
+from raytracer_amd.distributed import GpuSumsBackend, render_pass  # noqa: E402
+from raytracer_amd.scene import Scene  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, spec
+
+
+def load_scene(args) -> Scene:
+    """Generate (once) and parse the room scene.  The parsed arrays are cached
+    next to the generated OBJ so that several ranks do not each rebuild the BVH."""
+    root = os.path.join(ROOT, "assets_cache", f"room_d{args.detail}")
+    cache = os.path.join(root, "scene_v1.npz")
+    text = assets.room_scene_text("room", args.width, args.height, args.spp, args.bounces)
+    fields = ("spheres", "planes", "triangles", "vertex_normals", "tex_coords", "bary_precomputed", "materials",
+              "texels", "sphere_nodes", "plane_nodes", "triangle_nodes")
+    if os.path.exists(cache):
+        z = np.load(cache, allow_pickle=False)
+        params = parse(assets.room_scene_text("room", args.width, args.height, args.spp, args.bounces)
+                       .replace("obj((room/room))\n", ""), root).params
+        return Scene(params, *[z[k] for k in fields])
+    t0 = time.time()
+    if not os.path.exists(os.path.join(root, "obj", "room", "room.obj")):
+        assets.write_room(root, "room", detail=args.detail)
+    scene = parse(text, root)
+    tmp = cache + f".{os.getpid()}.tmp.npz"
+    np.savez(tmp, **{k: getattr(scene, k) for k in fields})
+    os.replace(tmp, cache)
+    print(f"[bench] scene generated, parsed and BVH built in {time.time() - t0:.1f}s "
+          f"({len(scene.triangles)} triangles, {len(scene.triangle_nodes)} nodes)", file=sys.stderr)
+    return scene
+
+
+def cpu_baseline(scene: Scene, args) -> dict:
+    """The CPU restatement of the reference's multithreaded renderer
+    (oracle/rt_oracle.c, pinned worker threads over pixel chunks), timed on this
+    box's host cores on a bounded sample of the same workload."""
+    from oracle import binding as O
+
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    p = scene.params.copy()
+    p.tile_w, p.tile_h = args.width // 2, args.height // 2
+    p.tile_x, p.tile_y = args.width // 4, args.height // 4
+    t0 = time.perf_counter()
+    O.render_sums(scene, p, 0, 1, threads=threads)
+    probe = time.perf_counter() - t0
+    spp = int(max(1, min(64, round(15.0 / max(probe, 1e-3)))))  # aim at about 15 s of CPU work
+    c = O.OracleCounters()
+    t0 = time.perf_counter()
+    O.render_sums(scene, p, 1, spp, threads=threads, counters=c)
+    dt = time.perf_counter() - t0
+    return {"value": round(c.segments / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"centre {p.tile_w}x{p.tile_h} tile of the same frame, {spp} spp, {args.bounces} bounces: "
+                      f"{c.segments} rays in {dt:.1f}s",
+            "rays_per_sample": round(c.segments / max(c.paths, 1), 3)}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--bounces", type=int, default=60)
+    ap.add_argument("--detail", type=int, default=4, help="tessellation of the generated room (4 = 2.9e5 triangles)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render loop has no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # rank 0 builds the cache first so the others only load it
+    if rank == 0:
+        scene = load_scene(args)
+    barrier()
+    if rank != 0:
+        scene = load_scene(args)
+
+    from raytracer_amd.renderer import Renderer
+
+    r = Renderer(local_rank)
+    r.upload(scene)
+    params = scene.params
+    backend = GpuSumsBackend(r, params, device)
+    rgb8 = np.zeros((args.height, args.width, 3), dtype=np.uint8)
+
+    def reduce_to_root(t):
+        dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+
+    def step():
+        sums = render_pass(backend, 0, args.spp, world, rank, reduce_to_root)
+        if rank == 0:
+            r.resolve(params, sums.data_ptr(), args.spp, rgb8=rgb8, sums_on_device=True)
+
+    # ---- traversal statistics of this workload (untimed, counting kernels)
+    count_spp = min(args.spp, 2)
+    r.set_option(F.RT_OPT_COUNT_TRAVERSAL, 1)
+    r.reset_stats()
+    backend.render_sums(0, count_spp)
+    cs = r.stats()
+    r.set_option(F.RT_OPT_COUNT_TRAVERSAL, 0)
+    seg = max(cs["segments"], 1)
+    B, T = cs["branch_visits"] / seg, cs["prim_tests"][2] / seg
+    S, P, H = cs["prim_tests"][0] / seg, cs["prim_tests"][1] / seg, cs["hits"] / seg
+    rays_per_path = cs["segments"] / max(cs["paths"], 1)
+
+    for _ in range(args.warmup):
+        step()
+    r.set_option(F.RT_OPT_TIME_KERNELS, 1)
+    r.reset_stats()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    st = r.stats()
+
+    agg = torch.tensor([dt, float(st["segments"]), float(st["paths"]), st["trace_ms"], float(st["trace_launches"])],
+                       dtype=torch.float64, device=device)
+    if world > 1:
+        mx = agg.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        dt = float(mx[0])
+    segments, paths = float(agg[1]), float(agg[2])
+
+    if rank == 0:
+        # Algorithmic bytes per ray on the reference's data sizes: each branch visit
+        # reads two 36-byte child nodes, each triangle test a 36-byte a/e1/e2.
+        # The dominant kernel is the triangle-BVH traversal; per ray it also reads
+        # the 24-byte ray and reads+writes the 12-byte hit record.
+        trace_bytes_per_ray = 72.0 * B + 36.0 * T + 24.0 + 2 * 12.0
+        whole_bytes_per_ray = 72.0 * B + 36.0 * T + 24.0 * S + 32.0 * P + 120.0 + 140.0 * H + 24.0 / rays_per_path
+        my_trace_ms, my_launches, my_segments = st["trace_ms"], max(st["trace_launches"], 1), st["segments"]
+        achieved = trace_bytes_per_ray * my_segments / (my_trace_ms / 1e3) / 1e9 if my_trace_ms > 0 else 0.0
+        rays_per_s = segments / dt
+        out = {
+            "metric": "Mrays/s (all bounces) breakfast-room 1080p",
+            "value": round(rays_per_s / 1e6, 3),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"breakfast-room-class generated room ({len(scene.triangles)} triangles, 5 ppm textures, "
+                            f"metal/glass/light spheres), {args.width}x{args.height}, {args.spp} spp, "
+                            f"{args.bounces} bounces, camera of scenes/breakfast-room",
+                "partition": "samples" if world > 1 else "none",
+                "collective": "reduce(sum) of f32 radiance per step" if world > 1 else "none",
+            },
+            "samples_per_s": round(paths / dt, 1),
+            "rays_per_sample": round(rays_per_path, 3),
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_trace<TRIANGLE>",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": None,
+                "bytes_per_ray": round(trace_bytes_per_ray, 1),
+                "avg_launch_ms": round(my_trace_ms / my_launches, 4),
+                "launches": int(my_launches),
+                "kernel_time_share": round(my_trace_ms / 1e3 / dt, 4),
+                "per_ray": {"branch_visits": round(B, 3), "triangle_tests": round(T, 3), "sphere_tests": round(S, 3),
+                            "plane_tests": round(P, 3), "hit_fraction": round(H, 4)},
+                "whole_path": {"bytes_per_ray": round(whole_bytes_per_ray, 1),
+                               "achieved": round(rays_per_s * whole_bytes_per_ray / 1e9, 2),
+                               "frac": round(rays_per_s * whole_bytes_per_ray / 1e9 / (HBM_PEAK_GBS * world), 5)},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, args)
+        print(json.dumps(out), flush=True)
+
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
