@@ -133,8 +133,10 @@ __device__ __forceinline__ bool triangle_hit(F3 a, F3 e1, F3 e2, F3 o, F3 d, flo
 
 // Persistent traversal kernel: one-wave workgroups; every lane owns one ray
 // and walks that ray's ordered stack exactly as bvh.rs:227-298 does.  Lanes
-// that finish fetch new rays from the queue through one wave-aggregated atomic
-// on the queue cursor, so a wave stays busy until the queue is drained.
+// that finish take new rays from a block of the queue the wave has reserved
+// (one atomic on the queue cursor per block of rays: a single shared counter
+// cannot serve one atomic per ray), so a wave stays busy until the queue is
+// drained.
 //
 // The stack's first kLdsSlots entries per lane live in LDS, laid out
 // [slot][lane] as 8-byte entries: lane l always touches banks 2l and 2l+1
@@ -144,6 +146,7 @@ __device__ __forceinline__ bool triangle_hit(F3 a, F3 e1, F3 e2, F3 o, F3 d, flo
 constexpr int kTraceBlock = 64;
 constexpr int kLdsSlots = 16;
 constexpr uint32_t kRefillMin = 1;  // refill as soon as this many lanes are idle
+constexpr uint32_t kChunkMax = 256; // most rays a wave reserves from the queue per atomic
 
 struct TraceArgs {
     DFamily fam;
@@ -162,6 +165,9 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
     const uint32_t gtid = blockIdx.x * kTraceBlock + lane;
     const uint32_t n = *a.n_rays;
     const DNode* __restrict__ nodes = a.fam.nodes;
+    // Reservation size: large for long queues (few atomics), one wave's worth for
+    // short ones so that the rays still spread over all waves of the grid.
+    const uint32_t chunk = min(kChunkMax, max(64u, (n / (2u * gridDim.x)) & ~63u));
 
     auto stack_store = [&](int slot, float dist, uint32_t ref) {
         const uint2 e = make_uint2(__float_as_uint(dist), ref);
@@ -174,6 +180,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
     };
 
     bool active = false, exhausted = false;
+    uint32_t pool_next = 0, pool_end = 0;  // wave-uniform: rays reserved for this wave
     uint32_t ray = 0, best_i = kHitNone;
     int sp = 0;
     F3 o = f3(0, 0, 0), d = f3(0, 0, 0);
@@ -181,31 +188,39 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
     unsigned long long n_branch = 0, n_tests = 0;
 
     for (;;) {
-        if (!exhausted) {
+        if (!exhausted || pool_next != pool_end) {
             const unsigned long long idle = __ballot(!active);
             const uint32_t n_idle = __popcll(idle);
             if (n_idle >= kRefillMin) {
-                const int leader = __ffsll(static_cast<long long>(idle)) - 1;
-                uint32_t base = 0;
-                if (static_cast<int>(lane) == leader) base = atomicAdd(a.cursor, n_idle);
-                base = __shfl(base, leader);
-                if (!active) {
-                    const uint32_t idx = base + __popcll(idle & ((1ull << lane) - 1ull));
-                    if (idx < n) {
-                        ray = idx;
-                        o = f3(a.q.origin[idx]);
-                        d = f3(a.q.direction[idx]);
-                        best_t = kInfinity;
-                        best_i = kHitNone;
-                        stack_store(0, 0.0f, a.fam.root_ref);  // bvh.rs:246, root box untested
-                        sp = 1;
-                        active = true;
-                    }
+                if (pool_next == pool_end) {
+                    // reserve the next block of the queue for this wave
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(a.cursor, chunk);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    pool_next = min(base, n);
+                    pool_end = min(base + chunk, n);
+                    if (base + chunk >= n) exhausted = true;
                 }
-                if (base + n_idle >= n) exhausted = true;
+                const uint32_t take = min(n_idle, pool_end - pool_next);
+                const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
+                if (!active && rank < take) {
+                    const uint32_t idx = pool_next + rank;
+                    ray = idx;
+                    o = f3(a.q.origin[idx]);
+                    d = f3(a.q.direction[idx]);
+                    best_t = kInfinity;
+                    best_i = kHitNone;
+                    stack_store(0, 0.0f, a.fam.root_ref);  // bvh.rs:246, root box untested
+                    sp = 1;
+                    active = true;
+                }
+                pool_next += take;
             }
         }
-        if (!__any(active)) break;
+        if (!__any(active)) {
+            if (exhausted && pool_next == pool_end) break;
+            continue;
+        }
 
         if (active) {
             if (sp == 0) {
