@@ -131,12 +131,63 @@ __device__ __forceinline__ bool triangle_hit(F3 a, F3 e1, F3 e2, F3 o, F3 d, flo
 
 // ------------------------------------------------------------------- trace
 
+// Exact division for the slab test at less than half the cost of `/`.
+//
+// hipcc expands a correctly rounded `a / b` into: scale both operands
+// (v_div_scale), r = rcp(b) refined by one Newton step, q = a*r refined by two
+// residual steps, then v_div_fmas / v_div_fixup for the scaled and special
+// cases — eleven instructions, four of which depend on b alone.  The slab test
+// divides twelve differences by the same three direction components per node,
+// so the reciprocal part is computed once per ray (refine_rcp) and each quotient
+// costs a multiply and four FMAs (div_by).  When no operand needs scaling this
+// is the very same operation sequence, hence the same bits.  The caller
+// guarantees that regime (see `fast` in k_trace): |b| in [2^-30, 2],
+// a == 0 or |a| in [2^-84, 2^60); anything else takes the plain `/`.
+// A zero quotient may come out with either sign; the slab test only compares.
+__device__ __forceinline__ float refine_rcp(float b) {
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, r0, 1.0f);
+    return __builtin_fmaf(e, r0, r0);
+}
+__device__ __forceinline__ float div_by(float a, float b, float r) {
+    float q = a * r;
+    float e = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(e, r, q);
+}
+
+// bvh.rs:25-43 with the quotients taken through div_by.
+__device__ __forceinline__ bool box_hit_fast(const float* mn, const float* mx, F3 o, F3 d, F3 r, float& tmin_out) {
+    const float t1x = div_by(mn[0] - o.x, d.x, r.x), t1y = div_by(mn[1] - o.y, d.y, r.y), t1z = div_by(mn[2] - o.z, d.z, r.z);
+    const float t2x = div_by(mx[0] - o.x, d.x, r.x), t2y = div_by(mx[1] - o.y, d.y, r.y), t2z = div_by(mx[2] - o.z, d.z, r.z);
+    const float tmin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
+    const float tmax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
+    tmin_out = tmin;
+    return tmax >= tmin && tmax > 0.0f;
+}
+
+// True when |v| is in [lo, hi) — false for NaN.
+__device__ __forceinline__ bool magnitude_in(float v, float lo, float hi) {
+    const float m = fabsf(v);
+    return m >= lo && m < hi;
+}
+
 // Persistent traversal kernel: one-wave workgroups; every lane owns one ray
 // and walks that ray's ordered stack exactly as bvh.rs:227-298 does.  Lanes
 // that finish take new rays from a block of the queue the wave has reserved
 // (one atomic on the queue cursor per block of rays: a single shared counter
 // cannot serve one atomic per ray), so a wave stays busy until the queue is
 // drained.
+//
+// A lane is always in one of three states: it needs to pop its stack, it holds
+// a popped branch waiting to be expanded, or it holds a leaf with shapes left
+// to test.  Every iteration the lanes that need to pop do so (cheap), then the
+// wave votes: the branch step (one 64-byte record, two slab tests, pushes) and
+// the shape step (one shape per lane) each run only when enough lanes wait for
+// them, so neither runs for a handful of lanes while the rest idle.  A lane's
+// own sequence of operations is never reordered, only delayed, so results are
+// those of the sequential algorithm.
 //
 // The stack's first kLdsSlots entries per lane live in LDS, laid out
 // [slot][lane] as 8-byte entries: lane l always touches banks 2l and 2l+1
@@ -145,8 +196,9 @@ __device__ __forceinline__ bool triangle_hit(F3 a, F3 e1, F3 e2, F3 o, F3 d, flo
 
 constexpr int kTraceBlock = 64;
 constexpr int kLdsSlots = 16;
-constexpr uint32_t kRefillMin = 1;  // refill as soon as this many lanes are idle
-constexpr uint32_t kChunkMax = 256; // most rays a wave reserves from the queue per atomic
+constexpr uint32_t kRefillMin = 1;   // refill as soon as this many lanes are idle
+constexpr uint32_t kChunkMax = 256;  // most rays a wave reserves from the queue per atomic
+constexpr uint32_t kPhaseMin = 24;   // a step runs for this many waiting lanes, or for the majority
 
 struct TraceArgs {
     DFamily fam;
@@ -155,6 +207,7 @@ struct TraceArgs {
     uint32_t* cursor;        // device: next unclaimed ray (zero before launch)
     uint2* spill;            // [(slot - kLdsSlots)][grid threads]
     uint32_t spill_stride;   // grid threads
+    int bounds_fast;         // every box coordinate is 0 or has magnitude in [2^-60, 2^59)
     unsigned long long* counters;  // [0] branch visits, [1] shape tests (COUNT only)
 };
 
@@ -179,12 +232,15 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
         return a.spill[static_cast<size_t>(slot - kLdsSlots) * a.spill_stride + gtid];
     };
 
-    bool active = false, exhausted = false;
+    bool active = false, exhausted = false, fast = false;
     uint32_t pool_next = 0, pool_end = 0;  // wave-uniform: rays reserved for this wave
     uint32_t ray = 0, best_i = kHitNone;
     int sp = 0;
-    F3 o = f3(0, 0, 0), d = f3(0, 0, 0);
+    F3 o = f3(0, 0, 0), d = f3(0, 0, 0), rcp = f3(0, 0, 0);
     float best_t = kInfinity;
+    bool have_branch = false;               // a popped branch waits to be expanded
+    uint32_t branch_ref = 0;
+    uint32_t shape_cur = 0, shape_end = 0;  // shapes of the current leaf still to test
     unsigned long long n_branch = 0, n_tests = 0;
 
     for (;;) {
@@ -213,6 +269,14 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
                     stack_store(0, 0.0f, a.fam.root_ref);  // bvh.rs:246, root box untested
                     sp = 1;
                     active = true;
+                    // regime in which div_by equals `/` (see above)
+                    fast = a.bounds_fast != 0 &&
+                           magnitude_in(d.x, 0x1p-30f, 2.0f) && magnitude_in(d.y, 0x1p-30f, 2.0f) &&
+                           magnitude_in(d.z, 0x1p-30f, 2.0f) &&
+                           (o.x == 0.0f || magnitude_in(o.x, 0x1p-60f, 0x1p59f)) &&
+                           (o.y == 0.0f || magnitude_in(o.y, 0x1p-60f, 0x1p59f)) &&
+                           (o.z == 0.0f || magnitude_in(o.z, 0x1p-60f, 0x1p59f));
+                    rcp = f3(refine_rcp(d.x), refine_rcp(d.y), refine_rcp(d.z));
                 }
                 pool_next += take;
             }
@@ -222,7 +286,8 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
             continue;
         }
 
-        if (active) {
+        // ---- pop: lanes with nothing in hand take the top of their stack
+        if (active && !have_branch && shape_cur == shape_end) {
             if (sp == 0) {
                 // bvh.rs:300 + lib.rs:333: keep the earlier family on equal distance.
                 if (best_t < a.q.hit_t[ray]) {
@@ -232,34 +297,11 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
                 active = false;
             } else {
                 const uint2 e = stack_load(--sp);
-                const float entry_dist = __uint_as_float(e.x);
-                const uint32_t ref = e.y;
-                if (!(best_t <= entry_dist)) {
+                if (!(best_t <= __uint_as_float(e.x))) {  // bvh.rs:252
+                    const uint32_t ref = e.y;
                     if (!(ref & kLeafBit)) {
-                        const DNode& nd = nodes[ref];
-                        const float4 q0 = reinterpret_cast<const float4*>(&nd)[0];
-                        const float4 q1 = reinterpret_cast<const float4*>(&nd)[1];
-                        const float4 q2 = reinterpret_cast<const float4*>(&nd)[2];
-                        const uint4 q3 = reinterpret_cast<const uint4*>(&nd)[3];
-                        const float c0min[3] = {q0.x, q0.y, q0.z}, c0max[3] = {q0.w, q1.x, q1.y};
-                        const float c1min[3] = {q1.z, q1.w, q2.x}, c1max[3] = {q2.y, q2.z, q2.w};
-                        float d0, d1;
-                        bool h0 = box_hit(c0min, c0max, o, d, d0);
-                        bool h1 = box_hit(c1min, c1max, o, d, d1);
-                        h0 = h0 && d0 < best_t;  // bvh.rs:263-266
-                        h1 = h1 && d1 < best_t;
-                        if (COUNT) ++n_branch;
-                        if (h0 && h1) {
-                            // bvh.rs:268-277: far child first; on a tie child 1 ends on top
-                            const bool zero_near = d0 < d1;
-                            stack_store(sp, zero_near ? d1 : d0, zero_near ? q3.y : q3.x);
-                            stack_store(sp + 1, zero_near ? d0 : d1, zero_near ? q3.x : q3.y);
-                            sp += 2;
-                        } else if (h0) {
-                            stack_store(sp++, d0, q3.x);
-                        } else if (h1) {
-                            stack_store(sp++, d1, q3.y);
-                        }
+                        have_branch = true;
+                        branch_ref = ref;
                     } else {
                         uint32_t first = ref & kLeafFirstMask;
                         uint32_t count = (ref >> kLeafCountShift) & 15u;
@@ -269,28 +311,72 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
                             count = ll.count;
                         }
                         if (COUNT) n_tests += count;
-                        // bvh.rs:288-295: ascending index, strict `<`
-                        for (uint32_t i = first; i < first + count; ++i) {
-                            float t;
-                            bool hit;
-                            if (KIND == 0) {
-                                hit = sphere_hit(static_cast<const DSphere*>(a.fam.shapes)[i], o, d, t);
-                            } else if (KIND == 1) {
-                                hit = plane_hit(static_cast<const DPlane*>(a.fam.shapes)[i], o, d, t);
-                            } else {
-                                const float4* tp = reinterpret_cast<const float4*>(
-                                    static_cast<const DTriangle*>(a.fam.shapes) + i);
-                                const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
-                                hit = triangle_hit(f3(v0.x, v0.y, v0.z), f3(v0.w, v1.x, v1.y),
-                                                   f3(v1.z, v1.w, v2.x), o, d, t);
-                            }
-                            if (hit && t < best_t) {
-                                best_t = t;
-                                best_i = i;
-                            }
-                        }
+                        shape_cur = first;
+                        shape_end = first + count;
                     }
                 }
+            }
+        }
+
+        // ---- vote on which steps are worth running this iteration
+        const bool want_shape = shape_cur < shape_end;
+        const uint32_t n_b = __popcll(__ballot(have_branch));
+        const uint32_t n_s = __popcll(__ballot(want_shape));
+        const bool run_branch = n_b >= kPhaseMin || (n_b > 0 && n_b >= n_s);
+        const bool run_shape = n_s >= kPhaseMin || n_s > n_b;
+
+        // ---- branch step: bvh.rs:259-286
+        if (run_branch && have_branch) {
+            have_branch = false;
+            const DNode& nd = nodes[branch_ref];
+            const float4 q0 = reinterpret_cast<const float4*>(&nd)[0];
+            const float4 q1 = reinterpret_cast<const float4*>(&nd)[1];
+            const float4 q2 = reinterpret_cast<const float4*>(&nd)[2];
+            const uint4 q3 = reinterpret_cast<const uint4*>(&nd)[3];
+            const float c0min[3] = {q0.x, q0.y, q0.z}, c0max[3] = {q0.w, q1.x, q1.y};
+            const float c1min[3] = {q1.z, q1.w, q2.x}, c1max[3] = {q2.y, q2.z, q2.w};
+            float d0, d1;
+            bool h0, h1;
+            if (fast) {
+                h0 = box_hit_fast(c0min, c0max, o, d, rcp, d0);
+                h1 = box_hit_fast(c1min, c1max, o, d, rcp, d1);
+            } else {
+                h0 = box_hit(c0min, c0max, o, d, d0);
+                h1 = box_hit(c1min, c1max, o, d, d1);
+            }
+            h0 = h0 && d0 < best_t;  // bvh.rs:263-266
+            h1 = h1 && d1 < best_t;
+            if (COUNT) ++n_branch;
+            if (h0 && h1) {
+                // bvh.rs:268-277: far child first; on a tie child 1 ends on top
+                const bool zero_near = d0 < d1;
+                stack_store(sp, zero_near ? d1 : d0, zero_near ? q3.y : q3.x);
+                stack_store(sp + 1, zero_near ? d0 : d1, zero_near ? q3.x : q3.y);
+                sp += 2;
+            } else if (h0) {
+                stack_store(sp++, d0, q3.x);
+            } else if (h1) {
+                stack_store(sp++, d1, q3.y);
+            }
+        }
+
+        // ---- shape step: the next shape of the leaf, bvh.rs:288-295 (ascending, strict `<`)
+        if (run_shape && want_shape) {
+            const uint32_t i = shape_cur++;
+            float t;
+            bool hit;
+            if (KIND == 0) {
+                hit = sphere_hit(static_cast<const DSphere*>(a.fam.shapes)[i], o, d, t);
+            } else if (KIND == 1) {
+                hit = plane_hit(static_cast<const DPlane*>(a.fam.shapes)[i], o, d, t);
+            } else {
+                const float4* tp = reinterpret_cast<const float4*>(static_cast<const DTriangle*>(a.fam.shapes) + i);
+                const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+                hit = triangle_hit(f3(v0.x, v0.y, v0.z), f3(v0.w, v1.x, v1.y), f3(v1.z, v1.w, v2.x), o, d, t);
+            }
+            if (hit && t < best_t) {
+                best_t = t;
+                best_i = i;
             }
         }
     }

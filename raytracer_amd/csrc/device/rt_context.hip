@@ -26,6 +26,7 @@ struct Family {
     uint32_t root_ref = kLeafBit;  // empty leaf
     uint32_t n_shapes = 0;
     uint32_t max_stack = 1;
+    bool bounds_fast = false;  // all box coordinates are 0 or of magnitude in [2^-60, 2^59)
 };
 
 struct Workspace {
@@ -157,6 +158,7 @@ int build_family(RtContext* ctx, const char* name, const RtNode* nodes, uint32_t
     out.n_shapes = n_shapes;
     out.root_ref = kLeafBit;
     out.max_stack = 1;
+    out.bounds_fast = false;
     if (n_nodes == 0) {
         if (n_shapes != 0) return fail(ctx, RT_ERR_INVALID, std::string(name) + ": shapes without a BVH");
         return RT_OK;
@@ -210,6 +212,19 @@ int build_family(RtContext* ctx, const char* name, const RtNode* nodes, uint32_t
     if (long_leaves.size() > kLeafFirstMask) return fail(ctx, RT_ERR_INVALID, std::string(name) + ": too many long leaves");
     out.root_ref = ref_of(0);
     out.max_stack = max_depth + 2;
+    // The kernels' cheaper exact division (div_by in kernels.h) is valid only when
+    // no slab-test numerator can be tiny or huge; that holds if every box
+    // coordinate is zero or of ordinary magnitude.  Infinite boxes (planes, empty
+    // families) and extreme scenes keep the plain division.
+    bool ordinary = true;
+    for (const DNode& r : branches) {
+        const float* c = r.c0min;  // the twelve box floats are contiguous
+        for (int k = 0; k < 12; ++k) {
+            const float m = std::fabs(c[k]);
+            if (!(m == 0.0f || (m >= 0x1p-60f && m < 0x1p59f))) ordinary = false;
+        }
+    }
+    out.bounds_fast = ordinary;
     return RT_OK;
 }
 
@@ -355,6 +370,7 @@ int launch_trace(RtContext* ctx, const DQueue& q, const uint32_t* n_rays, uint32
         a.cursor = cursors + kind;
         a.spill = ctx->ws.spill;
         a.spill_stride = ctx->trace_grid * kTraceBlock;
+        a.bounds_fast = ctx->fam[kind].bounds_fast ? 1 : 0;
         a.counters = ctx->d_stats + 1 + 2 * kind;  // [branch visits, shape tests] of this family
         const bool timed = ctx->opt_time && kind == RT_SHAPE_TRIANGLE;
         if (timed) {
