@@ -213,7 +213,11 @@ typedef struct RtStats {
 typedef enum RtOption {
     RT_OPT_COUNT_TRAVERSAL = 1, /* 0/1: fill branch_visits / prim_tests          */
     RT_OPT_TIME_KERNELS = 2,    /* 0/1: bracket traversal launches with events   */
-    RT_OPT_SAMPLES_IN_FLIGHT = 3 /* samples per pixel traced concurrently (>=1)  */
+    RT_OPT_SAMPLES_IN_FLIGHT = 3, /* samples per pixel traced concurrently (>=1) */
+    /* Tuning knobs of the traversal kernel; results never depend on them. */
+    RT_OPT_TRACE_LDS_SLOTS = 4, /* stack entries per ray kept in LDS (2..64)      */
+    RT_OPT_TRACE_PHASE_MIN = 5, /* lanes that must wait for a step to run it      */
+    RT_OPT_TRACE_CHUNK = 6      /* rays a wave reserves per queue atomic          */
 } RtOption;
 
 typedef struct RtContext RtContext;

@@ -189,47 +189,48 @@ __device__ __forceinline__ bool magnitude_in(float v, float lo, float hi) {
 // own sequence of operations is never reordered, only delayed, so results are
 // those of the sequential algorithm.
 //
-// The stack's first kLdsSlots entries per lane live in LDS, laid out
+// The stack's first `lds_slots` entries per lane live in LDS, laid out
 // [slot][lane] as 8-byte entries: lane l always touches banks 2l and 2l+1
 // (mod 64), whatever slot it is at, so divergent stack depths never conflict.
 // Deeper entries overflow to a private strip of global memory.
 
 constexpr int kTraceBlock = 64;
-constexpr int kLdsSlots = 16;
-constexpr uint32_t kRefillMin = 1;   // refill as soon as this many lanes are idle
-constexpr uint32_t kChunkMax = 256;  // most rays a wave reserves from the queue per atomic
-constexpr uint32_t kPhaseMin = 24;   // a step runs for this many waiting lanes, or for the majority
+constexpr uint32_t kRefillMin = 1;  // refill as soon as this many lanes are idle
 
 struct TraceArgs {
     DFamily fam;
     DQueue q;
     const uint32_t* n_rays;  // device: rays in the queue
     uint32_t* cursor;        // device: next unclaimed ray (zero before launch)
-    uint2* spill;            // [(slot - kLdsSlots)][grid threads]
+    uint2* spill;            // [(slot - lds_slots)][grid threads]
     uint32_t spill_stride;   // grid threads
+    uint32_t lds_slots;      // stack entries per lane kept in LDS (dynamic LDS = lds_slots*64*8 bytes)
+    uint32_t phase_min;      // a step runs for this many waiting lanes, or for the majority
+    uint32_t chunk_max;      // most rays a wave reserves from the queue per atomic
     int bounds_fast;         // every box coordinate is 0 or has magnitude in [2^-60, 2^59)
     unsigned long long* counters;  // [0] branch visits, [1] shape tests (COUNT only)
 };
 
 template <int KIND, bool COUNT>
 __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
-    __shared__ uint2 s_stack[kLdsSlots][kTraceBlock];
+    extern __shared__ __attribute__((aligned(16))) uint2 s_stack[];  // [lds_slots][64]
     const uint32_t lane = threadIdx.x;
     const uint32_t gtid = blockIdx.x * kTraceBlock + lane;
     const uint32_t n = *a.n_rays;
     const DNode* __restrict__ nodes = a.fam.nodes;
     // Reservation size: large for long queues (few atomics), one wave's worth for
     // short ones so that the rays still spread over all waves of the grid.
-    const uint32_t chunk = min(kChunkMax, max(64u, (n / (2u * gridDim.x)) & ~63u));
+    const uint32_t chunk = min(a.chunk_max, max(64u, (n / (2u * gridDim.x)) & ~63u));
+    const int lds_slots = static_cast<int>(a.lds_slots);
 
     auto stack_store = [&](int slot, float dist, uint32_t ref) {
         const uint2 e = make_uint2(__float_as_uint(dist), ref);
-        if (slot < kLdsSlots) s_stack[slot][lane] = e;
-        else a.spill[static_cast<size_t>(slot - kLdsSlots) * a.spill_stride + gtid] = e;
+        if (slot < lds_slots) s_stack[slot * kTraceBlock + lane] = e;
+        else a.spill[static_cast<size_t>(slot - lds_slots) * a.spill_stride + gtid] = e;
     };
     auto stack_load = [&](int slot) -> uint2 {
-        if (slot < kLdsSlots) return s_stack[slot][lane];
-        return a.spill[static_cast<size_t>(slot - kLdsSlots) * a.spill_stride + gtid];
+        if (slot < lds_slots) return s_stack[slot * kTraceBlock + lane];
+        return a.spill[static_cast<size_t>(slot - lds_slots) * a.spill_stride + gtid];
     };
 
     bool active = false, exhausted = false, fast = false;
@@ -322,8 +323,8 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
         const bool want_shape = shape_cur < shape_end;
         const uint32_t n_b = __popcll(__ballot(have_branch));
         const uint32_t n_s = __popcll(__ballot(want_shape));
-        const bool run_branch = n_b >= kPhaseMin || (n_b > 0 && n_b >= n_s);
-        const bool run_shape = n_s >= kPhaseMin || n_s > n_b;
+        const bool run_branch = n_b >= a.phase_min || (n_b > 0 && n_b >= n_s);
+        const bool run_shape = n_s >= a.phase_min || n_s > n_b;
 
         // ---- branch step: bvh.rs:259-286
         if (run_branch && have_branch) {
@@ -386,6 +387,47 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
     }
 }
 
+// --------------------------------------------------- inlined small families
+
+// Nearest hit of a new ray among the sphere and plane families that are small
+// enough to be scanned on the spot (DScene::inline_count).  A family whose BVH
+// is a single leaf is traversed by bvh.rs:288-295 as exactly this loop: shapes
+// in ascending index, replace on strict `<`; the later family replaces the
+// earlier only on strict `<` as well (lib.rs:333).  The result seeds the ray's
+// hit record; the traversal kernels of the remaining families merge into it.
+__device__ __forceinline__ void seed_hit(const DScene& sc, F3 o, F3 d, float& t_out, uint32_t& id_out,
+                                         unsigned long long* test_counters) {
+    float best_t = kInfinity;
+    uint32_t best_id = kHitNone;
+    const uint32_t ns = sc.inline_count[0], np = sc.inline_count[1];
+    for (uint32_t i = 0; i < ns; ++i) {
+        float t;
+        if (sphere_hit(static_cast<const DSphere*>(sc.family[0].shapes)[i], o, d, t) && t < best_t) {
+            best_t = t;
+            best_id = i;  // kind 0
+        }
+    }
+    float plane_t = kInfinity;
+    uint32_t plane_i = kHitNone;
+    for (uint32_t i = 0; i < np; ++i) {
+        float t;
+        if (plane_hit(static_cast<const DPlane*>(sc.family[1].shapes)[i], o, d, t) && t < plane_t) {
+            plane_t = t;
+            plane_i = i;
+        }
+    }
+    if (plane_t < best_t) {
+        best_t = plane_t;
+        best_id = (1u << kHitKindShift) | plane_i;
+    }
+    t_out = best_t;
+    id_out = best_id;
+    if (test_counters) {  // counting mode only
+        if (ns) atomicAdd(&test_counters[0], static_cast<unsigned long long>(ns));
+        if (np) atomicAdd(&test_counters[1], static_cast<unsigned long long>(np));
+    }
+}
+
 // ------------------------------------------------------------------ raygen
 
 struct FrameArgs {
@@ -399,8 +441,9 @@ struct FrameArgs {
 // lib.rs:261-268.  Path i of the batch is sample (first_sample + i / n_pixels)
 // of tile pixel (i % n_pixels); its generator starts at the sub-stream of
 // (sample, image pixel) and the two jitter draws come first, x then y.
-__global__ void k_raygen(FrameArgs f, DQueue q, uint32_t n_paths, uint32_t n_pixels,
-                         unsigned long long first_sample, int jitter, uint32_t* n_rays_out) {
+__global__ void k_raygen(FrameArgs f, DScene sc, DQueue q, uint32_t n_paths, uint32_t n_pixels,
+                         unsigned long long first_sample, int jitter, uint32_t* n_rays_out,
+                         unsigned long long* test_counters) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) *n_rays_out = n_paths;
     if (i >= n_paths) return;
@@ -426,20 +469,26 @@ __global__ void k_raygen(FrameArgs f, DQueue q, uint32_t n_paths, uint32_t n_pix
     q.throughput[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
     q.rng[i] = make_uint2(static_cast<uint32_t>(s), static_cast<uint32_t>(s >> 32));
     q.slot[i] = i;
-    q.hit_t[i] = kInfinity;
-    q.hit_id[i] = kHitNone;
+    float ht;
+    uint32_t hid;
+    seed_hit(sc, cam, dir, ht, hid, test_counters);
+    q.hit_t[i] = ht;
+    q.hit_id[i] = hid;
 }
 
 // Caller-supplied rays (rt_trace_rays).
-__global__ void k_load_rays(const float* origins, const float* directions, DQueue q, uint32_t n,
-                            uint32_t* n_rays_out) {
+__global__ void k_load_rays(const float* origins, const float* directions, DScene sc, DQueue q, uint32_t n,
+                            uint32_t* n_rays_out, unsigned long long* test_counters) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) *n_rays_out = n;
     if (i >= n) return;
     q.origin[i] = make_float4(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], 0.0f);
     q.direction[i] = make_float4(directions[3 * i], directions[3 * i + 1], directions[3 * i + 2], 0.0f);
-    q.hit_t[i] = kInfinity;
-    q.hit_id[i] = kHitNone;
+    float ht;
+    uint32_t hid;
+    seed_hit(sc, f3(q.origin[i]), f3(q.direction[i]), ht, hid, test_counters);
+    q.hit_t[i] = ht;
+    q.hit_id[i] = hid;
 }
 
 // ------------------------------------------------------------------- shade
@@ -471,13 +520,9 @@ __device__ __forceinline__ F3 color_sample(const DScene& sc, const DMaterial& m,
         i1[k] = min(e0 + 1u, dim[k] - 1u);
         de[k] = e - e0f;
     }
-    const uint8_t* tex = sc.texels + m.tex_offset;
+    const float4* tex = sc.texels + m.tex_first;
     const size_t w = m.tex_width;
-    auto texel = [&](uint32_t x, uint32_t y) {
-        const uint8_t* t = tex + 3 * (x + y * w);
-        return f3(static_cast<float>(t[0]) / 255.0f, static_cast<float>(t[1]) / 255.0f,
-                  static_cast<float>(t[2]) / 255.0f);
-    };
+    auto texel = [&](uint32_t x, uint32_t y) { return f3(tex[x + y * w]); };
     const F3 c00 = texel(i0[0], i0[1]), c01 = texel(i0[0], i1[1]);
     const F3 c10 = texel(i1[0], i0[1]), c11 = texel(i1[0], i1[1]);
     const float dx = de[0], dy = de[1];
@@ -493,6 +538,7 @@ struct ShadeArgs {
     uint32_t* n_next;       // zero before launch
     float4* result;         // [slot] final radiance of a finished path
     unsigned long long* hits;  // segments that hit something
+    unsigned long long* test_counters;  // [sphere tests, plane tests] of inlined families; null unless counting
     int last_bounce;        // this bounce is max_bounces-1
 };
 
@@ -545,28 +591,28 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
                         static_cast<const DTriangle*>(a.scene.family[2].shapes) + prim);
                     const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
                     const F3 ta = f3(v0.x, v0.y, v0.z), e1 = f3(v0.w, v1.x, v1.y), e2 = f3(v1.z, v1.w, v2.x);
-                    const DTriAttr at = a.scene.tri_attr[prim];
-                    mat_i = at.material;
-                    if (at.bary_idx == 0xFFFFFFFFu) {
+                    const float4* sp4 = reinterpret_cast<const float4*>(a.scene.tri_shade + prim);
+                    const float4 s3 = sp4[3];
+                    const uint32_t mf = __float_as_uint(s3.w);
+                    mat_i = mf & kTriMaterialMask;
+                    if (!(mf & kTriHasBary)) {
                         normal = normalize(cross(e1, e2));
                     } else {
                         // shapes.rs:210-227
-                        const float4 pre = reinterpret_cast<const float4*>(a.scene.bary_precomputed)[at.bary_idx];
+                        const float4 s0 = sp4[0], s1 = sp4[1], s2 = sp4[2], pre = sp4[4];
                         const F3 ap = p - ta;
                         const float d20 = dot(ap, e1), d21 = dot(ap, e2);
                         const float bv = (pre.z * d20 - pre.y * d21) / pre.w;
                         const float bw = (pre.x * d21 - pre.y * d20) / pre.w;
                         const float bu = 1.0f - bv - bw;
-                        if (at.normals_idx != 0xFFFFFFFFu) {
-                            const float* nn = a.scene.vertex_normals + 9 * static_cast<size_t>(at.normals_idx);
-                            normal = normalize((f3(nn) * bu + f3(nn + 3) * bv) + f3(nn + 6) * bw);
+                        if (mf & kTriHasNormals) {
+                            normal = normalize((f3(s0) * bu + f3(s1) * bv) + f3(s2) * bw);
                         } else {
                             normal = normalize(cross(e1, e2));
                         }
-                        if (at.uv_idx != 0xFFFFFFFFu) {
-                            const float* c = a.scene.tex_coords + 6 * static_cast<size_t>(at.uv_idx);
-                            uv0 = (c[0] * bu + c[2] * bv) + c[4] * bw;
-                            uv1 = (c[1] * bu + c[3] * bv) + c[5] * bw;
+                        if (mf & kTriHasUv) {
+                            uv0 = (s0.w * bu + s2.w * bv) + s3.y * bw;
+                            uv1 = (s1.w * bu + s3.x * bv) + s3.z * bw;
                         }
                     }
                 }
@@ -642,8 +688,11 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
                 a.next.throughput[dst] = make_float4(thr.x, thr.y, thr.z, 0.0f);
                 a.next.rng[dst] = make_uint2(static_cast<uint32_t>(rng), static_cast<uint32_t>(rng >> 32));
                 a.next.slot[dst] = slot;
-                a.next.hit_t[dst] = kInfinity;
-                a.next.hit_id[dst] = kHitNone;
+                float ht;
+                uint32_t hid;
+                seed_hit(a.scene, no, nd, ht, hid, a.test_counters);
+                a.next.hit_t[dst] = ht;
+                a.next.hit_id[dst] = hid;
             }
         }
     }
@@ -696,6 +745,16 @@ __global__ void k_quantize(const float* sums, uint8_t* rgb8, uint32_t n_values, 
         v = (old * k + corrected) / (k + 1.0f);
     }
     rgb8[i] = to_u8(v * 255.0f);
+}
+
+// Upload-time expansion of one texture: packed RGB8 -> float4(byte/255), the
+// per-channel conversion of vec3.rs:515-520 (true division, done once).
+__global__ void k_expand_texels(const uint8_t* rgb8, float4* out, unsigned long long n_texels) {
+    const unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n_texels) return;
+    const uint8_t* t = rgb8 + 3 * i;
+    out[i] = make_float4(static_cast<float>(t[0]) / 255.0f, static_cast<float>(t[1]) / 255.0f,
+                         static_cast<float>(t[2]) / 255.0f, 0.0f);
 }
 
 }  // namespace rtd

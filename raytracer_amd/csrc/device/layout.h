@@ -69,18 +69,38 @@ struct DLongLeaf {
     uint32_t first, count;
 };
 
-// Per-triangle shading attributes (NormalsTextureCoordinates + material).
-struct alignas(16) DTriAttr {
-    uint32_t normals_idx, uv_idx, bary_idx, material;
+// Everything the shade step needs about a triangle besides its geometry, in
+// five aligned 16-byte words addressed by the triangle's own index (the
+// reference reaches the same values through three per-triangle indices into
+// side tables, /root/reference/src/shapes.rs:264-326 and src/lib.rs:114-122).
+constexpr uint32_t kTriHasBary = 0x80000000u;     // barycentric table row present
+constexpr uint32_t kTriHasNormals = 0x40000000u;  // vertex normals present
+constexpr uint32_t kTriHasUv = 0x20000000u;       // texture coordinates present
+constexpr uint32_t kTriMaterialMask = 0x1FFFFFFFu;
+struct alignas(16) DTriShade {
+    float n0[3];
+    float uv0x;
+    float n1[3];
+    float uv0y;
+    float n2[3];
+    float uv1x;
+    float uv1y, uv2x, uv2y;
+    uint32_t material_flags;  // material index | kTriHas* bits
+    float d00, d01, d11, den; // barycentric precomputation, /root/reference/src/obj.rs:142-153
 };
+static_assert(sizeof(DTriShade) == 80, "shading record is five 16-byte loads");
 
+// Textures are expanded at upload from packed RGB8 to one float4 per texel
+// holding byte/255 (the division of /root/reference/src/vec3.rs:515-520 done
+// once per texel instead of once per fetch), so a bilinear lookup is four
+// aligned 16-byte loads and no arithmetic on bytes.
 struct DMaterial {
     uint32_t kind;
     float param;
     uint32_t color_kind;
     float rgb[3];
     uint32_t tex_width, tex_height;
-    uint64_t tex_offset;
+    uint64_t tex_first;  // index of the texture's first texel in DScene::texels
 };
 
 // One shape family's acceleration structure on the device.
@@ -97,12 +117,13 @@ struct DScene {
     DFamily family[3];
     const uint32_t* sphere_material;
     const uint32_t* plane_material;
-    const DTriAttr* tri_attr;
-    const float* vertex_normals;    // [n][3][3]
-    const float* tex_coords;        // [n][3][2]
-    const float* bary_precomputed;  // [n][4]
+    const DTriShade* tri_shade;
     const DMaterial* materials;
-    const uint8_t* texels;
+    const float4* texels;
+    // A sphere or plane family whose whole BVH is one small leaf is not given a
+    // traversal launch of its own: the kernel that creates a ray scans those few
+    // shapes at once (same ascending order, same strict `<`).  0 = not inlined.
+    uint32_t inline_count[2];
 };
 
 // One bounce's worth of live paths.

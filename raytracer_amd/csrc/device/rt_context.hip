@@ -54,20 +54,23 @@ struct RtContext {
     Family fam[3];
     uint32_t* sphere_material = nullptr;
     uint32_t* plane_material = nullptr;
-    DTriAttr* tri_attr = nullptr;
-    float* vertex_normals = nullptr;
-    float* tex_coords = nullptr;
-    float* bary = nullptr;
+    DTriShade* tri_shade = nullptr;
     DMaterial* materials = nullptr;
-    uint8_t* texels = nullptr;
+    float4* texels = nullptr;
     uint32_t n_materials = 0;
+    uint32_t inline_count[2] = {0, 0};  // spheres / planes scanned where rays are created
 
     Workspace ws;
-    unsigned long long* d_stats = nullptr;  // hits, then {branch visits, shape tests} per family
+    unsigned long long* d_stats = nullptr;  // hits, then {branch visits, shape tests} per family, then
+                                            // {sphere tests, plane tests} of inlined families
+    unsigned long long* d_inline_tests = nullptr;  // = d_stats + 7
     uint32_t* h_pinned = nullptr;           // small pinned read-back area
     size_t h_pinned_words = 0;
 
-    uint32_t trace_grid = 0;
+    uint32_t trace_grid = 0;       // workgroups of the persistent traversal kernel
+    uint32_t trace_grid_slots = 0; // the lds_slots value trace_grid was sized for
+    uint32_t max_grid_threads = 0; // upper bound of trace_grid * 64 (sizes the spill area)
+    uint32_t tune_lds_slots = 8, tune_phase_min = 24, tune_chunk_max = 256;
     bool opt_count = false, opt_time = false;
     uint64_t opt_samples_in_flight = 0;  // 0 = automatic
     std::vector<hipEvent_t> events;      // pairs around timed launches
@@ -78,7 +81,7 @@ struct RtContext {
 
 namespace {
 
-constexpr size_t kStatWords = 7;
+constexpr size_t kStatWords = 9;
 
 int fail(RtContext* ctx, int code, const std::string& msg) {
     if (ctx) ctx->error = msg;
@@ -111,17 +114,14 @@ void free_scene(RtContext* ctx) {
     }
     (void)hipFree(ctx->sphere_material);
     (void)hipFree(ctx->plane_material);
-    (void)hipFree(ctx->tri_attr);
-    (void)hipFree(ctx->vertex_normals);
-    (void)hipFree(ctx->tex_coords);
-    (void)hipFree(ctx->bary);
+    (void)hipFree(ctx->tri_shade);
     (void)hipFree(ctx->materials);
     (void)hipFree(ctx->texels);
     ctx->sphere_material = ctx->plane_material = nullptr;
-    ctx->tri_attr = nullptr;
-    ctx->vertex_normals = ctx->tex_coords = ctx->bary = nullptr;
+    ctx->tri_shade = nullptr;
     ctx->materials = nullptr;
     ctx->texels = nullptr;
+    ctx->inline_count[0] = ctx->inline_count[1] = 0;
     ctx->has_scene = false;
 }
 
@@ -340,29 +340,48 @@ DScene device_scene(const RtContext* ctx) {
     }
     s.sphere_material = ctx->sphere_material;
     s.plane_material = ctx->plane_material;
-    s.tri_attr = ctx->tri_attr;
-    s.vertex_normals = ctx->vertex_normals;
-    s.tex_coords = ctx->tex_coords;
-    s.bary_precomputed = ctx->bary;
+    s.tri_shade = ctx->tri_shade;
     s.materials = ctx->materials;
     s.texels = ctx->texels;
+    s.inline_count[0] = ctx->inline_count[0];
+    s.inline_count[1] = ctx->inline_count[1];
     return s;
 }
 
+// Where the kernels that scan inlined families add their shape-test counts
+// (the "shape tests" words of the sphere and plane families); null unless
+// counting is on.  d_stats: [0] hits, then {branch visits, shape tests} x 3.
+unsigned long long* inline_counters(RtContext* ctx) { return ctx->opt_count ? ctx->d_inline_tests : nullptr; }
+
 template <int KIND>
 void launch_trace_kind(RtContext* ctx, const TraceArgs& a) {
+    const size_t lds = static_cast<size_t>(a.lds_slots) * kTraceBlock * sizeof(uint2);
     if (ctx->opt_count)
-        hipLaunchKernelGGL((k_trace<KIND, true>), dim3(ctx->trace_grid), dim3(kTraceBlock), 0, ctx->stream, a);
+        hipLaunchKernelGGL((k_trace<KIND, true>), dim3(ctx->trace_grid), dim3(kTraceBlock), lds, ctx->stream, a);
     else
-        hipLaunchKernelGGL((k_trace<KIND, false>), dim3(ctx->trace_grid), dim3(kTraceBlock), 0, ctx->stream, a);
+        hipLaunchKernelGGL((k_trace<KIND, false>), dim3(ctx->trace_grid), dim3(kTraceBlock), lds, ctx->stream, a);
+}
+
+// Size the persistent grid to what is resident at once for the current LDS use.
+void size_trace_grid(RtContext* ctx) {
+    if (ctx->trace_grid && ctx->trace_grid_slots == ctx->tune_lds_slots) return;
+    int per_cu = 0;
+    const size_t lds = static_cast<size_t>(ctx->tune_lds_slots) * kTraceBlock * sizeof(uint2);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<2, false>, kTraceBlock, lds) != hipSuccess || per_cu < 1)
+        per_cu = 8;
+    per_cu = std::min(per_cu, 32);
+    ctx->trace_grid = static_cast<uint32_t>(ctx->n_cus) * static_cast<uint32_t>(per_cu);
+    ctx->trace_grid_slots = ctx->tune_lds_slots;
 }
 
 // Nearest hit of every ray in `q` over the three families, in the reference's
 // order (lib.rs:314-333).  `cursors` points at three zeroed words.
 int launch_trace(RtContext* ctx, const DQueue& q, const uint32_t* n_rays, uint32_t* cursors) {
     const DScene sc = device_scene(ctx);
+    size_trace_grid(ctx);
     for (int kind = 0; kind < 3; ++kind) {
         if (ctx->fam[kind].n_shapes == 0) continue;  // an empty family can never be hit
+        if (kind < 2 && ctx->inline_count[kind]) continue;  // already scanned when the ray was created
         TraceArgs a{};
         a.fam = sc.family[kind];
         a.q = q;
@@ -370,6 +389,9 @@ int launch_trace(RtContext* ctx, const DQueue& q, const uint32_t* n_rays, uint32
         a.cursor = cursors + kind;
         a.spill = ctx->ws.spill;
         a.spill_stride = ctx->trace_grid * kTraceBlock;
+        a.lds_slots = ctx->tune_lds_slots;
+        a.phase_min = ctx->tune_phase_min;
+        a.chunk_max = ctx->tune_chunk_max;
         a.bounds_fast = ctx->fam[kind].bounds_fast ? 1 : 0;
         a.counters = ctx->d_stats + 1 + 2 * kind;  // [branch visits, shape tests] of this family
         const bool timed = ctx->opt_time && kind == RT_SHAPE_TRIANGLE;
@@ -414,6 +436,8 @@ int harvest(RtContext* ctx) {
         ctx->stats.branch_visits += h[1 + 2 * kind];
         ctx->stats.prim_tests[kind] += h[2 + 2 * kind];
     }
+    ctx->stats.prim_tests[0] += h[7];
+    ctx->stats.prim_tests[1] += h[8];
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof h, ctx->stream));
     return RT_OK;
 }
@@ -421,7 +445,7 @@ int harvest(RtContext* ctx) {
 size_t choose_samples_in_flight(const RtContext* ctx, size_t n_pixels, uint32_t count) {
     size_t s = ctx->opt_samples_in_flight;
     if (s == 0) {
-        const size_t target_paths = size_t{1} << 23;  // enough to keep every CU busy through the tail
+        const size_t target_paths = size_t{1} << 26;  // long queues amortise the thin tail of late bounces
         s = std::max<size_t>(1, target_paths / std::max<size_t>(n_pixels, 1));
     }
     s = std::min<size_t>(s, count);
@@ -455,8 +479,8 @@ int render_sums_device(RtContext* ctx, const RtRenderParams* p, const Region& r,
             // lib.rs:313,374: no bounce, no colour -> black
             HIP_TRY(ctx, hipMemsetAsync(w.result, 0, static_cast<size_t>(n_paths) * sizeof(float4), ctx->stream));
         } else {
-            hipLaunchKernelGGL(k_raygen, dim3((n_paths + 255) / 256), dim3(256), 0, ctx->stream, f, w.q[0], n_paths,
-                               n_pix, static_cast<unsigned long long>(s_begin) + b0, 1, counts);
+            hipLaunchKernelGGL(k_raygen, dim3((n_paths + 255) / 256), dim3(256), 0, ctx->stream, f, sc, w.q[0], n_paths,
+                               n_pix, static_cast<unsigned long long>(s_begin) + b0, 1, counts, inline_counters(ctx));
             HIP_TRY(ctx, hipGetLastError());
         }
         ctx->stats.paths += n_paths;
@@ -473,6 +497,7 @@ int render_sums_device(RtContext* ctx, const RtRenderParams* p, const Region& r,
             sa.n_next = counts + b + 1;
             sa.result = w.result;
             sa.hits = ctx->d_stats;
+            sa.test_counters = inline_counters(ctx);
             sa.last_bounce = b + 1 == B;
             hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(256), 0, ctx->stream, sa);
             HIP_TRY(ctx, hipGetLastError());
@@ -557,11 +582,9 @@ int rt_create(int device_ordinal, RtContext** out) {
         delete ctx;
         return RT_ERR_HIP;
     }
+    ctx->d_inline_tests = ctx->d_stats + 7;
     ctx->n_cus = prop.multiProcessorCount;
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<2, false>, kTraceBlock, 0) != hipSuccess || per_cu < 1)
-        per_cu = 8;
-    ctx->trace_grid = static_cast<uint32_t>(ctx->n_cus) * static_cast<uint32_t>(per_cu);
+    ctx->max_grid_threads = static_cast<uint32_t>(ctx->n_cus) * 32u * kTraceBlock;  // 32 waves per CU at most
     *out = ctx;
     return RT_OK;
 }
@@ -587,6 +610,18 @@ int rt_set_option(RtContext* ctx, uint32_t option, uint64_t value) {
         case RT_OPT_COUNT_TRAVERSAL: ctx->opt_count = value != 0; return RT_OK;
         case RT_OPT_TIME_KERNELS: ctx->opt_time = value != 0; return RT_OK;
         case RT_OPT_SAMPLES_IN_FLIGHT: ctx->opt_samples_in_flight = value; return RT_OK;
+        case RT_OPT_TRACE_LDS_SLOTS:
+            if (value < 2 || value > 64) return fail(ctx, RT_ERR_INVALID, "lds slots must be in 2..64");
+            ctx->tune_lds_slots = static_cast<uint32_t>(value);
+            return RT_OK;
+        case RT_OPT_TRACE_PHASE_MIN:
+            if (value < 1 || value > 64) return fail(ctx, RT_ERR_INVALID, "phase threshold must be in 1..64");
+            ctx->tune_phase_min = static_cast<uint32_t>(value);
+            return RT_OK;
+        case RT_OPT_TRACE_CHUNK:
+            if (value < 64 || value > 4096 || value % 64) return fail(ctx, RT_ERR_INVALID, "chunk must be a multiple of 64 in 64..4096");
+            ctx->tune_chunk_max = static_cast<uint32_t>(value);
+            return RT_OK;
         default: return fail(ctx, RT_ERR_INVALID, "unknown option");
     }
 }
@@ -663,19 +698,64 @@ int rt_upload_scene(RtContext* ctx, const RtSceneDesc* s) {
             pm[i] = s->planes[i].material;
         }
         std::vector<DTriangle> tr(s->n_triangles);
-        std::vector<DTriAttr> ta(s->n_triangles);
+        std::vector<DTriShade> ts(s->n_triangles);
         for (uint32_t i = 0; i < s->n_triangles; ++i) {
             const RtTriangle& t = s->triangles[i];
             std::memcpy(tr[i].a, t.a, 12);
             std::memcpy(tr[i].e1, t.e1, 12);
             std::memcpy(tr[i].e2, t.e2, 12);
             tr[i].pad[0] = tr[i].pad[1] = tr[i].pad[2] = 0.0f;
-            ta[i] = DTriAttr{t.normals_idx, t.uv_idx, t.bary_idx, t.material};
+            DTriShade& d = ts[i];
+            std::memset(&d, 0, sizeof d);
+            if (t.material > kTriMaterialMask) { free_scene(ctx); return fail(ctx, RT_ERR_INVALID, "too many materials"); }
+            d.material_flags = t.material;
+            if (t.bary_idx != RT_NO_INDEX) {
+                const float* b = s->bary_precomputed + 4 * static_cast<size_t>(t.bary_idx);
+                d.d00 = b[0]; d.d01 = b[1]; d.d11 = b[2]; d.den = b[3];
+                d.material_flags |= kTriHasBary;
+            }
+            if (t.normals_idx != RT_NO_INDEX) {
+                const float* n = s->vertex_normals + 9 * static_cast<size_t>(t.normals_idx);
+                std::memcpy(d.n0, n, 12);
+                std::memcpy(d.n1, n + 3, 12);
+                std::memcpy(d.n2, n + 6, 12);
+                d.material_flags |= kTriHasNormals;
+            }
+            if (t.uv_idx != RT_NO_INDEX) {
+                const float* c = s->tex_coords + 6 * static_cast<size_t>(t.uv_idx);
+                d.uv0x = c[0]; d.uv0y = c[1]; d.uv1x = c[2]; d.uv1y = c[3]; d.uv2x = c[4]; d.uv2y = c[5];
+                d.material_flags |= kTriHasUv;
+            }
         }
+        // textures: one float4 per texel, each texture contiguous
         std::vector<DMaterial> mats(s->n_materials);
+        uint64_t n_texels = 0;
         for (uint32_t i = 0; i < s->n_materials; ++i) {
             const RtMaterial& m = s->materials[i];
-            mats[i] = DMaterial{m.kind, m.param, m.color_kind, {m.rgb[0], m.rgb[1], m.rgb[2]}, m.tex_width, m.tex_height, m.tex_offset};
+            mats[i] = DMaterial{m.kind, m.param, m.color_kind, {m.rgb[0], m.rgb[1], m.rgb[2]}, m.tex_width, m.tex_height, 0};
+            if (m.color_kind == RT_COLOR_TEXTURE) {
+                mats[i].tex_first = n_texels;
+                n_texels += static_cast<uint64_t>(m.tex_width) * m.tex_height;
+            }
+        }
+        {
+            uint8_t* d_rgb8 = nullptr;
+            int rc = upload(ctx, &d_rgb8, s->texels, static_cast<size_t>(s->n_texel_bytes));
+            if (!rc) {
+                hipError_t e = hipMalloc(reinterpret_cast<void**>(&ctx->texels), std::max<uint64_t>(n_texels, 1) * sizeof(float4));
+                if (e != hipSuccess) rc = fail(ctx, RT_ERR_OOM, "texture memory");
+            }
+            for (uint32_t i = 0; !rc && i < s->n_materials; ++i) {
+                const RtMaterial& m = s->materials[i];
+                if (m.color_kind != RT_COLOR_TEXTURE) continue;
+                const unsigned long long nt = static_cast<unsigned long long>(m.tex_width) * m.tex_height;
+                hipLaunchKernelGGL(k_expand_texels, dim3(static_cast<uint32_t>((nt + 255) / 256)), dim3(256), 0, nullptr,
+                                   d_rgb8 + m.tex_offset, ctx->texels + mats[i].tex_first, nt);
+                if (hipGetLastError() != hipSuccess) rc = fail(ctx, RT_ERR_HIP, "texture expansion launch failed");
+            }
+            if (hipDeviceSynchronize() != hipSuccess && !rc) rc = fail(ctx, RT_ERR_HIP, "texture expansion failed");
+            (void)hipFree(d_rgb8);
+            if (rc) { free_scene(ctx); return rc; }
         }
         DSphere* dsp = nullptr;
         DPlane* dpl = nullptr;
@@ -686,22 +766,26 @@ int rt_upload_scene(RtContext* ctx, const RtSceneDesc* s) {
         if (!rc) { rc = upload(ctx, &dtr, tr.data(), tr.size()); ctx->fam[2].shapes = dtr; }
         if (!rc) rc = upload(ctx, &ctx->sphere_material, sm.data(), sm.size());
         if (!rc) rc = upload(ctx, &ctx->plane_material, pm.data(), pm.size());
-        if (!rc) rc = upload(ctx, &ctx->tri_attr, ta.data(), ta.size());
-        if (!rc) rc = upload(ctx, &ctx->vertex_normals, s->vertex_normals, static_cast<size_t>(s->n_vertex_normals) * 9);
-        if (!rc) rc = upload(ctx, &ctx->tex_coords, s->tex_coords, static_cast<size_t>(s->n_tex_coords) * 6);
-        if (!rc) rc = upload(ctx, &ctx->bary, s->bary_precomputed, static_cast<size_t>(s->n_bary) * 4);
+        if (!rc) rc = upload(ctx, &ctx->tri_shade, ts.data(), ts.size());
         if (!rc) rc = upload(ctx, &ctx->materials, mats.data(), mats.size());
-        if (!rc) rc = upload(ctx, &ctx->texels, s->texels, static_cast<size_t>(s->n_texel_bytes));
         if (rc) { free_scene(ctx); return rc; }
         ctx->n_materials = s->n_materials;
+        // Sphere / plane families that are one small leaf are scanned where rays are
+        // created instead of getting traversal launches of their own.
+        constexpr uint32_t kInlineMax = 16;
+        for (int k = 0; k < 2; ++k) {
+            const bool single_leaf = node_counts[k] == 1 && (node_arrays[k][0].b & RT_LEAF_BIT) && node_arrays[k][0].a == 0 &&
+                                     (node_arrays[k][0].b & ~RT_LEAF_BIT) == shape_counts[k];
+            ctx->inline_count[k] = single_leaf && shape_counts[k] <= kInlineMax ? shape_counts[k] : 0;
+        }
     }
     HIP_TRY(ctx, hipDeviceSynchronize());  // uploads above went through the default stream
 
     // ---- stack overflow area for trees deeper than the LDS part of the stack
     {
         Workspace& w = ctx->ws;
-        const size_t extra = deepest > static_cast<uint32_t>(kLdsSlots) ? deepest - kLdsSlots : 0;
-        const size_t entries = std::max<size_t>(1, extra * ctx->trace_grid * kTraceBlock);
+        // sized for the whole stack so that any LDS share (down to none) is safe
+        const size_t entries = std::max<size_t>(1, static_cast<size_t>(deepest) * ctx->max_grid_threads);
         if (w.spill_entries < entries) {
             (void)hipFree(w.spill);
             w.spill = nullptr;
@@ -801,8 +885,8 @@ int rt_trace_primary(RtContext* ctx, const RtRenderParams* p, uint32_t sample_in
     const FrameArgs f = frame_args(p, r);
     const uint32_t n = static_cast<uint32_t>(r.n_pixels);
     HIP_TRY(ctx, hipMemsetAsync(w.counters, 0, 8 * sizeof(uint32_t), ctx->stream));
-    hipLaunchKernelGGL(k_raygen, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, f, w.q[0], n, n,
-                       static_cast<unsigned long long>(sample_index), jitter ? 1 : 0, w.counters);
+    hipLaunchKernelGGL(k_raygen, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, f, device_scene(ctx), w.q[0], n, n,
+                       static_cast<unsigned long long>(sample_index), jitter ? 1 : 0, w.counters, inline_counters(ctx));
     HIP_TRY(ctx, hipGetLastError());
     rc = launch_trace(ctx, w.q[0], w.counters, w.counters + 2);
     if (rc) return rc;
@@ -828,7 +912,8 @@ int rt_trace_rays(RtContext* ctx, const float* origins, const float* directions,
     HIP_TRY(ctx, hipMemcpyAsync(d_o, origins, n_rays * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(d_d, directions, n_rays * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(w.counters, 0, 8 * sizeof(uint32_t), ctx->stream));
-    hipLaunchKernelGGL(k_load_rays, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_o, d_d, w.q[0], n, w.counters);
+    hipLaunchKernelGGL(k_load_rays, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_o, d_d, device_scene(ctx), w.q[0], n,
+                       w.counters, inline_counters(ctx));
     HIP_TRY(ctx, hipGetLastError());
     rc = launch_trace(ctx, w.q[0], w.counters, w.counters + 2);
     if (rc) return rc;
