@@ -494,7 +494,8 @@ __global__ void k_load_rays(const float* origins, const float* directions, DScen
 // ------------------------------------------------------------------- shade
 
 // material.rs:192-239
-__device__ __forceinline__ F3 color_sample(const DScene& sc, const DMaterial& m, float u_in, float v_in) {
+__device__ __forceinline__ F3 color_sample(const DScene& sc, const DMaterial& m, float u_in, float v_in,
+                                           const float* unit_of_byte) {
     if (m.color_kind == 0) return f3(m.rgb);
     float c[2] = {u_in, v_in};
 #pragma unroll
@@ -520,9 +521,13 @@ __device__ __forceinline__ F3 color_sample(const DScene& sc, const DMaterial& m,
         i1[k] = min(e0 + 1u, dim[k] - 1u);
         de[k] = e - e0f;
     }
-    const float4* tex = sc.texels + m.tex_first;
+    const uint32_t* tex = sc.texels + m.tex_first;
     const size_t w = m.tex_width;
-    auto texel = [&](uint32_t x, uint32_t y) { return f3(tex[x + y * w]); };
+    // byte -> byte/255 (vec3.rs:515-520) through a 256-entry table of exact quotients
+    auto texel = [&](uint32_t x, uint32_t y) {
+        const uint32_t t = tex[x + y * w];
+        return f3(unit_of_byte[t & 255u], unit_of_byte[(t >> 8) & 255u], unit_of_byte[(t >> 16) & 255u]);
+    };
     const F3 c00 = texel(i0[0], i0[1]), c01 = texel(i0[0], i1[1]);
     const F3 c10 = texel(i1[0], i0[1]), c11 = texel(i1[0], i1[1]);
     const float dx = de[0], dy = de[1];
@@ -546,8 +551,14 @@ struct ShadeArgs {
 // lib.rs:335-371, with Material::scatter (material.rs:23-100) and the surface
 // attributes of shapes.rs:91-99,157-165,264-326 inlined.
 __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
+    __shared__ float s_unit[256];      // byte/255, all 256 quotients by true division
+    __shared__ uint32_t s_wave_live[4];
+    __shared__ uint32_t s_block_base;
+    s_unit[threadIdx.x] = static_cast<float>(threadIdx.x) / 255.0f;
+    __syncthreads();
     const uint32_t n = *a.n_cur;
     const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t rounds = (n + stride - 1) / stride;
     unsigned long long my_hits = 0;
@@ -587,32 +598,30 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
                     normal = f3(pl.normal);
                     mat_i = a.scene.plane_material[prim];
                 } else {
-                    const float4* tp = reinterpret_cast<const float4*>(
-                        static_cast<const DTriangle*>(a.scene.family[2].shapes) + prim);
-                    const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
-                    const F3 ta = f3(v0.x, v0.y, v0.z), e1 = f3(v0.w, v1.x, v1.y), e2 = f3(v1.z, v1.w, v2.x);
-                    const float4* sp4 = reinterpret_cast<const float4*>(a.scene.tri_shade + prim);
-                    const float4 s3 = sp4[3];
-                    const uint32_t mf = __float_as_uint(s3.w);
+                    const float4* sp4 = reinterpret_cast<const float4*>(a.scene.tri_surface + prim);
+                    const float4 w0 = sp4[0], w1 = sp4[1], w2 = sp4[2], w7 = sp4[7];
+                    const F3 ta = f3(w0.x, w0.y, w0.z), e1 = f3(w0.w, w1.x, w1.y), e2 = f3(w1.z, w1.w, w2.x);
+                    const uint32_t mf = __float_as_uint(w7.x);
                     mat_i = mf & kTriMaterialMask;
                     if (!(mf & kTriHasBary)) {
                         normal = normalize(cross(e1, e2));
                     } else {
                         // shapes.rs:210-227
-                        const float4 s0 = sp4[0], s1 = sp4[1], s2 = sp4[2], pre = sp4[4];
+                        const float4 w3 = sp4[3], w4 = sp4[4], w5 = sp4[5], pre = sp4[6];
                         const F3 ap = p - ta;
                         const float d20 = dot(ap, e1), d21 = dot(ap, e2);
                         const float bv = (pre.z * d20 - pre.y * d21) / pre.w;
                         const float bw = (pre.x * d21 - pre.y * d20) / pre.w;
                         const float bu = 1.0f - bv - bw;
                         if (mf & kTriHasNormals) {
-                            normal = normalize((f3(s0) * bu + f3(s1) * bv) + f3(s2) * bw);
+                            const F3 n0 = f3(w2.y, w2.z, w2.w), n1 = f3(w3.x, w3.y, w3.z), n2 = f3(w3.w, w4.x, w4.y);
+                            normal = normalize((n0 * bu + n1 * bv) + n2 * bw);
                         } else {
                             normal = normalize(cross(e1, e2));
                         }
                         if (mf & kTriHasUv) {
-                            uv0 = (s0.w * bu + s2.w * bv) + s3.y * bw;
-                            uv1 = (s1.w * bu + s3.x * bv) + s3.z * bw;
+                            uv0 = (w4.z * bu + w5.x * bv) + w5.z * bw;
+                            uv1 = (w4.w * bu + w5.y * bv) + w5.w * bw;
                         }
                     }
                 }
@@ -663,7 +672,7 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
                 if (what == 1) {
                     a.result[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // lib.rs:359-362
                 } else {
-                    thr = thr * color_sample(a.scene, m, uv0, uv1);
+                    thr = thr * color_sample(a.scene, m, uv0, uv1, s_unit);
                     if (what == 2 || a.last_bounce) {
                         // a light ends the path; so does the bounce limit, which
                         // returns the throughput reached so far (lib.rs:313,374)
@@ -674,27 +683,30 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
                 }
             }
         }
-        // compaction: one atomic per wave, survivors keep their relative order
+        // compaction: one atomic per workgroup and round; survivors keep their order
         const unsigned long long live = __ballot(alive);
-        if (live) {
-            const int leader = __ffsll(static_cast<long long>(live)) - 1;
-            uint32_t base = 0;
-            if (static_cast<int>(lane) == leader) base = atomicAdd(a.n_next, __popcll(live));
-            base = __shfl(base, leader);
-            if (alive) {
-                const uint32_t dst = base + __popcll(live & ((1ull << lane) - 1ull));
-                a.next.origin[dst] = make_float4(no.x, no.y, no.z, 0.0f);
-                a.next.direction[dst] = make_float4(nd.x, nd.y, nd.z, 0.0f);
-                a.next.throughput[dst] = make_float4(thr.x, thr.y, thr.z, 0.0f);
-                a.next.rng[dst] = make_uint2(static_cast<uint32_t>(rng), static_cast<uint32_t>(rng >> 32));
-                a.next.slot[dst] = slot;
-                float ht;
-                uint32_t hid;
-                seed_hit(a.scene, no, nd, ht, hid, a.test_counters);
-                a.next.hit_t[dst] = ht;
-                a.next.hit_id[dst] = hid;
-            }
+        if (lane == 0) s_wave_live[wave] = __popcll(live);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t total = s_wave_live[0] + s_wave_live[1] + s_wave_live[2] + s_wave_live[3];
+            s_block_base = total ? atomicAdd(a.n_next, total) : 0u;
         }
+        __syncthreads();
+        if (alive) {
+            uint32_t dst = s_block_base + __popcll(live & ((1ull << lane) - 1ull));
+            for (uint32_t k = 0; k < wave; ++k) dst += s_wave_live[k];
+            a.next.origin[dst] = make_float4(no.x, no.y, no.z, 0.0f);
+            a.next.direction[dst] = make_float4(nd.x, nd.y, nd.z, 0.0f);
+            a.next.throughput[dst] = make_float4(thr.x, thr.y, thr.z, 0.0f);
+            a.next.rng[dst] = make_uint2(static_cast<uint32_t>(rng), static_cast<uint32_t>(rng >> 32));
+            a.next.slot[dst] = slot;
+            float ht;
+            uint32_t hid;
+            seed_hit(a.scene, no, nd, ht, hid, a.test_counters);
+            a.next.hit_t[dst] = ht;
+            a.next.hit_id[dst] = hid;
+        }
+        __syncthreads();  // s_wave_live / s_block_base are rewritten next round
     }
     // one atomic per wave for the hit counter
     for (int off = 32; off > 0; off >>= 1) my_hits += __shfl_down(my_hits, off);
@@ -747,14 +759,12 @@ __global__ void k_quantize(const float* sums, uint8_t* rgb8, uint32_t n_values, 
     rgb8[i] = to_u8(v * 255.0f);
 }
 
-// Upload-time expansion of one texture: packed RGB8 -> float4(byte/255), the
-// per-channel conversion of vec3.rs:515-520 (true division, done once).
-__global__ void k_expand_texels(const uint8_t* rgb8, float4* out, unsigned long long n_texels) {
+// Upload-time repacking of one texture: packed RGB8 -> one 32-bit word per texel.
+__global__ void k_expand_texels(const uint8_t* rgb8, uint32_t* out, unsigned long long n_texels) {
     const unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n_texels) return;
     const uint8_t* t = rgb8 + 3 * i;
-    out[i] = make_float4(static_cast<float>(t[0]) / 255.0f, static_cast<float>(t[1]) / 255.0f,
-                         static_cast<float>(t[2]) / 255.0f, 0.0f);
+    out[i] = static_cast<uint32_t>(t[0]) | (static_cast<uint32_t>(t[1]) << 8) | (static_cast<uint32_t>(t[2]) << 16);
 }
 
 }  // namespace rtd

@@ -69,31 +69,29 @@ struct DLongLeaf {
     uint32_t first, count;
 };
 
-// Everything the shade step needs about a triangle besides its geometry, in
-// five aligned 16-byte words addressed by the triangle's own index (the
-// reference reaches the same values through three per-triangle indices into
-// side tables, /root/reference/src/shapes.rs:264-326 and src/lib.rs:114-122).
+// Everything the shade step needs about a triangle — geometry, vertex normals,
+// texture coordinates, the barycentric precomputation and the material — in
+// one 128-byte, 128-byte-aligned record addressed by the triangle's own index,
+// so shading a hit costs one memory line.  (The reference reaches the same
+// values through three per-triangle indices into side tables,
+// /root/reference/src/shapes.rs:264-326 and src/lib.rs:114-122; traversal keeps
+// its own compact 48-byte geometry array.)
 constexpr uint32_t kTriHasBary = 0x80000000u;     // barycentric table row present
 constexpr uint32_t kTriHasNormals = 0x40000000u;  // vertex normals present
 constexpr uint32_t kTriHasUv = 0x20000000u;       // texture coordinates present
 constexpr uint32_t kTriMaterialMask = 0x1FFFFFFFu;
-struct alignas(16) DTriShade {
-    float n0[3];
-    float uv0x;
-    float n1[3];
-    float uv0y;
-    float n2[3];
-    float uv1x;
-    float uv1y, uv2x, uv2y;
-    uint32_t material_flags;  // material index | kTriHas* bits
-    float d00, d01, d11, den; // barycentric precomputation, /root/reference/src/obj.rs:142-153
+struct alignas(128) DTriSurface {
+    float a[3], e1[3], e2[3];      // words 0..8
+    float n0[3], n1[3], n2[3];     // words 9..17
+    float uv0[2], uv1[2], uv2[2];  // words 18..23
+    float d00, d01, d11, den;      // words 24..27, /root/reference/src/obj.rs:142-153
+    uint32_t material_flags;       // word 28: material index | kTriHas* bits
+    uint32_t pad[3];
 };
-static_assert(sizeof(DTriShade) == 80, "shading record is five 16-byte loads");
+static_assert(sizeof(DTriSurface) == 128, "surface record is one 128-byte line");
 
-// Textures are expanded at upload from packed RGB8 to one float4 per texel
-// holding byte/255 (the division of /root/reference/src/vec3.rs:515-520 done
-// once per texel instead of once per fetch), so a bilinear lookup is four
-// aligned 16-byte loads and no arithmetic on bytes.
+// Textures are repacked at upload from 3 to 4 bytes per texel (R, G, B, unused)
+// so that a texel is one aligned 32-bit load; each texture is contiguous.
 struct DMaterial {
     uint32_t kind;
     float param;
@@ -117,9 +115,9 @@ struct DScene {
     DFamily family[3];
     const uint32_t* sphere_material;
     const uint32_t* plane_material;
-    const DTriShade* tri_shade;
+    const DTriSurface* tri_surface;
     const DMaterial* materials;
-    const float4* texels;
+    const uint32_t* texels;  // R | G<<8 | B<<16
     // A sphere or plane family whose whole BVH is one small leaf is not given a
     // traversal launch of its own: the kernel that creates a ray scans those few
     // shapes at once (same ascending order, same strict `<`).  0 = not inlined.

@@ -54,9 +54,9 @@ struct RtContext {
     Family fam[3];
     uint32_t* sphere_material = nullptr;
     uint32_t* plane_material = nullptr;
-    DTriShade* tri_shade = nullptr;
+    DTriSurface* tri_surface = nullptr;
     DMaterial* materials = nullptr;
-    float4* texels = nullptr;
+    uint32_t* texels = nullptr;
     uint32_t n_materials = 0;
     uint32_t inline_count[2] = {0, 0};  // spheres / planes scanned where rays are created
 
@@ -114,11 +114,11 @@ void free_scene(RtContext* ctx) {
     }
     (void)hipFree(ctx->sphere_material);
     (void)hipFree(ctx->plane_material);
-    (void)hipFree(ctx->tri_shade);
+    (void)hipFree(ctx->tri_surface);
     (void)hipFree(ctx->materials);
     (void)hipFree(ctx->texels);
     ctx->sphere_material = ctx->plane_material = nullptr;
-    ctx->tri_shade = nullptr;
+    ctx->tri_surface = nullptr;
     ctx->materials = nullptr;
     ctx->texels = nullptr;
     ctx->inline_count[0] = ctx->inline_count[1] = 0;
@@ -340,7 +340,7 @@ DScene device_scene(const RtContext* ctx) {
     }
     s.sphere_material = ctx->sphere_material;
     s.plane_material = ctx->plane_material;
-    s.tri_shade = ctx->tri_shade;
+    s.tri_surface = ctx->tri_surface;
     s.materials = ctx->materials;
     s.texels = ctx->texels;
     s.inline_count[0] = ctx->inline_count[0];
@@ -698,15 +698,18 @@ int rt_upload_scene(RtContext* ctx, const RtSceneDesc* s) {
             pm[i] = s->planes[i].material;
         }
         std::vector<DTriangle> tr(s->n_triangles);
-        std::vector<DTriShade> ts(s->n_triangles);
+        std::vector<DTriSurface> ts(s->n_triangles);
         for (uint32_t i = 0; i < s->n_triangles; ++i) {
             const RtTriangle& t = s->triangles[i];
             std::memcpy(tr[i].a, t.a, 12);
             std::memcpy(tr[i].e1, t.e1, 12);
             std::memcpy(tr[i].e2, t.e2, 12);
             tr[i].pad[0] = tr[i].pad[1] = tr[i].pad[2] = 0.0f;
-            DTriShade& d = ts[i];
+            DTriSurface& d = ts[i];
             std::memset(&d, 0, sizeof d);
+            std::memcpy(d.a, t.a, 12);
+            std::memcpy(d.e1, t.e1, 12);
+            std::memcpy(d.e2, t.e2, 12);
             if (t.material > kTriMaterialMask) { free_scene(ctx); return fail(ctx, RT_ERR_INVALID, "too many materials"); }
             d.material_flags = t.material;
             if (t.bary_idx != RT_NO_INDEX) {
@@ -723,11 +726,13 @@ int rt_upload_scene(RtContext* ctx, const RtSceneDesc* s) {
             }
             if (t.uv_idx != RT_NO_INDEX) {
                 const float* c = s->tex_coords + 6 * static_cast<size_t>(t.uv_idx);
-                d.uv0x = c[0]; d.uv0y = c[1]; d.uv1x = c[2]; d.uv1y = c[3]; d.uv2x = c[4]; d.uv2y = c[5];
+                std::memcpy(d.uv0, c, 8);
+                std::memcpy(d.uv1, c + 2, 8);
+                std::memcpy(d.uv2, c + 4, 8);
                 d.material_flags |= kTriHasUv;
             }
         }
-        // textures: one float4 per texel, each texture contiguous
+        // textures: one 32-bit word per texel, each texture contiguous
         std::vector<DMaterial> mats(s->n_materials);
         uint64_t n_texels = 0;
         for (uint32_t i = 0; i < s->n_materials; ++i) {
@@ -742,7 +747,7 @@ int rt_upload_scene(RtContext* ctx, const RtSceneDesc* s) {
             uint8_t* d_rgb8 = nullptr;
             int rc = upload(ctx, &d_rgb8, s->texels, static_cast<size_t>(s->n_texel_bytes));
             if (!rc) {
-                hipError_t e = hipMalloc(reinterpret_cast<void**>(&ctx->texels), std::max<uint64_t>(n_texels, 1) * sizeof(float4));
+                hipError_t e = hipMalloc(reinterpret_cast<void**>(&ctx->texels), std::max<uint64_t>(n_texels, 1) * sizeof(uint32_t));
                 if (e != hipSuccess) rc = fail(ctx, RT_ERR_OOM, "texture memory");
             }
             for (uint32_t i = 0; !rc && i < s->n_materials; ++i) {
@@ -766,7 +771,7 @@ int rt_upload_scene(RtContext* ctx, const RtSceneDesc* s) {
         if (!rc) { rc = upload(ctx, &dtr, tr.data(), tr.size()); ctx->fam[2].shapes = dtr; }
         if (!rc) rc = upload(ctx, &ctx->sphere_material, sm.data(), sm.size());
         if (!rc) rc = upload(ctx, &ctx->plane_material, pm.data(), pm.size());
-        if (!rc) rc = upload(ctx, &ctx->tri_shade, ts.data(), ts.size());
+        if (!rc) rc = upload(ctx, &ctx->tri_surface, ts.data(), ts.size());
         if (!rc) rc = upload(ctx, &ctx->materials, mats.data(), mats.size());
         if (rc) { free_scene(ctx); return rc; }
         ctx->n_materials = s->n_materials;
