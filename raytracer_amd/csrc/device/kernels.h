@@ -157,14 +157,17 @@ __device__ __forceinline__ float div_by(float a, float b, float r) {
     return __builtin_fmaf(e, r, q);
 }
 
-// bvh.rs:25-43 with the quotients taken through div_by.
-__device__ __forceinline__ bool box_hit_fast(const float* mn, const float* mx, F3 o, F3 d, F3 r, float& tmin_out) {
-    const float t1x = div_by(mn[0] - o.x, d.x, r.x), t1y = div_by(mn[1] - o.y, d.y, r.y), t1z = div_by(mn[2] - o.z, d.z, r.z);
-    const float t2x = div_by(mx[0] - o.x, d.x, r.x), t2y = div_by(mx[1] - o.y, d.y, r.y), t2z = div_by(mx[2] - o.z, d.z, r.z);
-    const float tmin = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
-    const float tmax = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
-    tmin_out = tmin;
-    return tmax >= tmin && tmax > 0.0f;
+// Two quotients with a common divisor in one packed instruction stream
+// (v_pk_mul_f32 / v_pk_fma_f32 carry two binary32 operations per lane, each
+// rounded exactly like its scalar form).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f div_by2(v2f a, float b, float r) {
+    const v2f nb = {-b, -b}, rr = {r, r};
+    v2f q = a * rr;
+    v2f e = __builtin_elementwise_fma(nb, q, a);
+    q = __builtin_elementwise_fma(e, rr, q);
+    e = __builtin_elementwise_fma(nb, q, a);
+    return __builtin_elementwise_fma(e, rr, q);
 }
 
 // True when |v| is in [lo, hi) — false for NaN.
@@ -174,20 +177,22 @@ __device__ __forceinline__ bool magnitude_in(float v, float lo, float hi) {
 }
 
 // Persistent traversal kernel: one-wave workgroups; every lane owns one ray
-// and walks that ray's ordered stack exactly as bvh.rs:227-298 does.  Lanes
-// that finish take new rays from a block of the queue the wave has reserved
-// (one atomic on the queue cursor per block of rays: a single shared counter
-// cannot serve one atomic per ray), so a wave stays busy until the queue is
-// drained.
+// and performs that ray's ordered traversal exactly as bvh.rs:227-298 does.
+// Lanes that finish take new rays from a block of the queue the wave has
+// reserved (one atomic on the queue cursor per block of rays: a single shared
+// counter cannot serve one atomic per ray), so a wave stays busy until the
+// queue is drained.
 //
-// A lane is always in one of three states: it needs to pop its stack, it holds
-// a popped branch waiting to be expanded, or it holds a leaf with shapes left
-// to test.  Every iteration the lanes that need to pop do so (cheap), then the
-// wave votes: the branch step (one 64-byte record, two slab tests, pushes) and
-// the shape step (one shape per lane) each run only when enough lanes wait for
-// them, so neither runs for a handful of lanes while the rest idle.  A lane's
-// own sequence of operations is never reordered, only delayed, so results are
-// those of the sequential algorithm.
+// What a lane holds between iterations is either a branch to expand, a leaf
+// with shapes left to test, or nothing (then it pops its stack).  Expanding a
+// branch pushes only the farther child: the nearer one would be pushed last and
+// popped first with the cull test of bvh.rs:252 already known to pass (it was
+// pushed because its distance is below the closest hit, which has not changed),
+// so it is kept in hand instead of making the round trip through the stack.
+// Every iteration the wave votes: the branch step (one 64-byte record, two slab
+// tests) and the shape step (one shape per lane) each run only when enough
+// lanes wait for them.  A lane's own sequence of operations is never reordered,
+// only delayed, so results are those of the sequential algorithm.
 //
 // The stack's first `lds_slots` entries per lane live in LDS, laid out
 // [slot][lane] as 8-byte entries: lane l always touches banks 2l and 2l+1
@@ -195,7 +200,7 @@ __device__ __forceinline__ bool magnitude_in(float v, float lo, float hi) {
 // Deeper entries overflow to a private strip of global memory.
 
 constexpr int kTraceBlock = 64;
-constexpr uint32_t kRefillMin = 1;  // refill as soon as this many lanes are idle
+constexpr uint32_t kItemNone = 0xFFFFFFFFu;
 
 struct TraceArgs {
     DFamily fam;
@@ -239,16 +244,15 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
     int sp = 0;
     F3 o = f3(0, 0, 0), d = f3(0, 0, 0), rcp = f3(0, 0, 0);
     float best_t = kInfinity;
-    bool have_branch = false;               // a popped branch waits to be expanded
-    uint32_t branch_ref = 0;
+    uint32_t item = kItemNone;              // node reference in hand (branch or leaf)
     uint32_t shape_cur = 0, shape_end = 0;  // shapes of the current leaf still to test
     unsigned long long n_branch = 0, n_tests = 0;
 
     for (;;) {
         if (!exhausted || pool_next != pool_end) {
             const unsigned long long idle = __ballot(!active);
-            const uint32_t n_idle = __popcll(idle);
-            if (n_idle >= kRefillMin) {
+            if (idle) {
+                const uint32_t n_idle = __popcll(idle);
                 if (pool_next == pool_end) {
                     // reserve the next block of the queue for this wave
                     uint32_t base = 0;
@@ -267,16 +271,16 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
                     d = f3(a.q.direction[idx]);
                     best_t = kInfinity;
                     best_i = kHitNone;
-                    stack_store(0, 0.0f, a.fam.root_ref);  // bvh.rs:246, root box untested
-                    sp = 1;
+                    sp = 0;
+                    item = a.fam.root_ref;  // bvh.rs:246: the root is entered with its box untested
                     active = true;
-                    // regime in which div_by equals `/` (see above)
-                    fast = a.bounds_fast != 0 &&
-                           magnitude_in(d.x, 0x1p-30f, 2.0f) && magnitude_in(d.y, 0x1p-30f, 2.0f) &&
-                           magnitude_in(d.z, 0x1p-30f, 2.0f) &&
-                           (o.x == 0.0f || magnitude_in(o.x, 0x1p-60f, 0x1p59f)) &&
-                           (o.y == 0.0f || magnitude_in(o.y, 0x1p-60f, 0x1p59f)) &&
-                           (o.z == 0.0f || magnitude_in(o.z, 0x1p-60f, 0x1p59f));
+                    // regime in which div_by2 equals `/` (see refine_rcp)
+                    const int d_ok = int(magnitude_in(d.x, 0x1p-30f, 2.0f)) & int(magnitude_in(d.y, 0x1p-30f, 2.0f)) &
+                                     int(magnitude_in(d.z, 0x1p-30f, 2.0f));
+                    const int o_ok = (int(o.x == 0.0f) | int(magnitude_in(o.x, 0x1p-60f, 0x1p59f))) &
+                                     (int(o.y == 0.0f) | int(magnitude_in(o.y, 0x1p-60f, 0x1p59f))) &
+                                     (int(o.z == 0.0f) | int(magnitude_in(o.z, 0x1p-60f, 0x1p59f)));
+                    fast = (int(a.bounds_fast != 0) & d_ok & o_ok) != 0;
                     rcp = f3(refine_rcp(d.x), refine_rcp(d.y), refine_rcp(d.z));
                 }
                 pool_next += take;
@@ -287,97 +291,106 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
             continue;
         }
 
-        // ---- pop: lanes with nothing in hand take the top of their stack
-        if (active && !have_branch && shape_cur == shape_end) {
-            if (sp == 0) {
+        // ---- pop: a lane with nothing in hand takes the first stack entry that
+        //      survives the cull test of bvh.rs:252, or finishes its ray
+        if (active && item == kItemNone && shape_cur == shape_end) {
+            while (sp > 0) {
+                const uint2 e = stack_load(--sp);
+                if (!(best_t <= __uint_as_float(e.x))) {
+                    item = e.y;
+                    break;
+                }
+            }
+            if (item == kItemNone) {
                 // bvh.rs:300 + lib.rs:333: keep the earlier family on equal distance.
                 if (best_t < a.q.hit_t[ray]) {
                     a.q.hit_t[ray] = best_t;
                     a.q.hit_id[ray] = (static_cast<uint32_t>(KIND) << kHitKindShift) | best_i;
                 }
                 active = false;
-            } else {
-                const uint2 e = stack_load(--sp);
-                if (!(best_t <= __uint_as_float(e.x))) {  // bvh.rs:252
-                    const uint32_t ref = e.y;
-                    if (!(ref & kLeafBit)) {
-                        have_branch = true;
-                        branch_ref = ref;
-                    } else {
-                        uint32_t first = ref & kLeafFirstMask;
-                        uint32_t count = (ref >> kLeafCountShift) & 15u;
-                        if (count == kLeafLong) {
-                            const DLongLeaf ll = a.fam.long_leaves[first];
-                            first = ll.first;
-                            count = ll.count;
-                        }
-                        if (COUNT) n_tests += count;
-                        shape_cur = first;
-                        shape_end = first + count;
-                    }
+            }
+        }
+
+        // ---- branch step, bvh.rs:259-286
+        const bool want_branch = item < kLeafBit;  // kItemNone and leaves have the top bit set
+        {
+            const uint32_t n_b = __popcll(__ballot(want_branch));
+            const uint32_t n_s = __popcll(__ballot(shape_cur < shape_end));
+            if (n_b > 0 && (n_b >= a.phase_min || n_b >= n_s) && want_branch) {
+                const float4* np = reinterpret_cast<const float4*>(nodes + item);
+                const float4 qx = np[0], qy = np[1], qz = np[2];  // (c0min, c1min, c0max, c1max) per axis
+                const uint4 q3 = reinterpret_cast<const uint4*>(np)[3];
+                float d0, d1;
+                bool h0, h1;
+                if (fast) {
+                    const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+                    const v2f t1x = div_by2(v2f{qx.x, qx.y} - ox, d.x, rcp.x), t2x = div_by2(v2f{qx.z, qx.w} - ox, d.x, rcp.x);
+                    const v2f t1y = div_by2(v2f{qy.x, qy.y} - oy, d.y, rcp.y), t2y = div_by2(v2f{qy.z, qy.w} - oy, d.y, rcp.y);
+                    const v2f t1z = div_by2(v2f{qz.x, qz.y} - oz, d.z, rcp.z), t2z = div_by2(v2f{qz.z, qz.w} - oz, d.z, rcp.z);
+                    d0 = fmaxf(fmaxf(fminf(t1x.x, t2x.x), fminf(t1y.x, t2y.x)), fminf(t1z.x, t2z.x));
+                    d1 = fmaxf(fmaxf(fminf(t1x.y, t2x.y), fminf(t1y.y, t2y.y)), fminf(t1z.y, t2z.y));
+                    const float f0 = fminf(fminf(fmaxf(t1x.x, t2x.x), fmaxf(t1y.x, t2y.x)), fmaxf(t1z.x, t2z.x));
+                    const float f1 = fminf(fminf(fmaxf(t1x.y, t2x.y), fmaxf(t1y.y, t2y.y)), fmaxf(t1z.y, t2z.y));
+                    h0 = f0 >= d0 && f0 > 0.0f;
+                    h1 = f1 >= d1 && f1 > 0.0f;
+                } else {
+                    const float c0min[3] = {qx.x, qy.x, qz.x}, c0max[3] = {qx.z, qy.z, qz.z};
+                    const float c1min[3] = {qx.y, qy.y, qz.y}, c1max[3] = {qx.w, qy.w, qz.w};
+                    h0 = box_hit(c0min, c0max, o, d, d0);
+                    h1 = box_hit(c1min, c1max, o, d, d1);
+                }
+                h0 = h0 && d0 < best_t;  // bvh.rs:263-266
+                h1 = h1 && d1 < best_t;
+                if (COUNT) ++n_branch;
+                // bvh.rs:268-285.  With both children hit the farther one is pushed and
+                // the nearer kept in hand; on equal distances child 1 is the nearer.
+                const bool zero_near = d0 < d1;
+                if (h0 && h1) {
+                    stack_store(sp++, zero_near ? d1 : d0, zero_near ? q3.y : q3.x);
+                    item = zero_near ? q3.x : q3.y;
+                } else {
+                    item = h0 ? q3.x : (h1 ? q3.y : kItemNone);
                 }
             }
         }
 
-        // ---- vote on which steps are worth running this iteration
-        const bool want_shape = shape_cur < shape_end;
-        const uint32_t n_b = __popcll(__ballot(have_branch));
-        const uint32_t n_s = __popcll(__ballot(want_shape));
-        const bool run_branch = n_b >= a.phase_min || (n_b > 0 && n_b >= n_s);
-        const bool run_shape = n_s >= a.phase_min || n_s > n_b;
-
-        // ---- branch step: bvh.rs:259-286
-        if (run_branch && have_branch) {
-            have_branch = false;
-            const DNode& nd = nodes[branch_ref];
-            const float4 q0 = reinterpret_cast<const float4*>(&nd)[0];
-            const float4 q1 = reinterpret_cast<const float4*>(&nd)[1];
-            const float4 q2 = reinterpret_cast<const float4*>(&nd)[2];
-            const uint4 q3 = reinterpret_cast<const uint4*>(&nd)[3];
-            const float c0min[3] = {q0.x, q0.y, q0.z}, c0max[3] = {q0.w, q1.x, q1.y};
-            const float c1min[3] = {q1.z, q1.w, q2.x}, c1max[3] = {q2.y, q2.z, q2.w};
-            float d0, d1;
-            bool h0, h1;
-            if (fast) {
-                h0 = box_hit_fast(c0min, c0max, o, d, rcp, d0);
-                h1 = box_hit_fast(c1min, c1max, o, d, rcp, d1);
-            } else {
-                h0 = box_hit(c0min, c0max, o, d, d0);
-                h1 = box_hit(c1min, c1max, o, d, d1);
+        // ---- a leaf in hand becomes a range of shapes to test
+        if (item != kItemNone && item >= kLeafBit) {
+            uint32_t first = item & kLeafFirstMask;
+            uint32_t count = (item >> kLeafCountShift) & 15u;
+            if (count == kLeafLong) {
+                const DLongLeaf ll = a.fam.long_leaves[first];
+                first = ll.first;
+                count = ll.count;
             }
-            h0 = h0 && d0 < best_t;  // bvh.rs:263-266
-            h1 = h1 && d1 < best_t;
-            if (COUNT) ++n_branch;
-            if (h0 && h1) {
-                // bvh.rs:268-277: far child first; on a tie child 1 ends on top
-                const bool zero_near = d0 < d1;
-                stack_store(sp, zero_near ? d1 : d0, zero_near ? q3.y : q3.x);
-                stack_store(sp + 1, zero_near ? d0 : d1, zero_near ? q3.x : q3.y);
-                sp += 2;
-            } else if (h0) {
-                stack_store(sp++, d0, q3.x);
-            } else if (h1) {
-                stack_store(sp++, d1, q3.y);
-            }
+            if (COUNT) n_tests += count;
+            shape_cur = first;
+            shape_end = first + count;
+            item = kItemNone;
         }
 
         // ---- shape step: the next shape of the leaf, bvh.rs:288-295 (ascending, strict `<`)
-        if (run_shape && want_shape) {
-            const uint32_t i = shape_cur++;
-            float t;
-            bool hit;
-            if (KIND == 0) {
-                hit = sphere_hit(static_cast<const DSphere*>(a.fam.shapes)[i], o, d, t);
-            } else if (KIND == 1) {
-                hit = plane_hit(static_cast<const DPlane*>(a.fam.shapes)[i], o, d, t);
-            } else {
-                const float4* tp = reinterpret_cast<const float4*>(static_cast<const DTriangle*>(a.fam.shapes) + i);
-                const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
-                hit = triangle_hit(f3(v0.x, v0.y, v0.z), f3(v0.w, v1.x, v1.y), f3(v1.z, v1.w, v2.x), o, d, t);
-            }
-            if (hit && t < best_t) {
-                best_t = t;
-                best_i = i;
+        {
+            const bool want_shape = shape_cur < shape_end;
+            const uint32_t n_s = __popcll(__ballot(want_shape));
+            const uint32_t n_b = __popcll(__ballot(item < kLeafBit));
+            if (n_s > 0 && (n_s >= a.phase_min || n_s >= n_b) && want_shape) {
+                const uint32_t i = shape_cur++;
+                float t;
+                bool hit;
+                if (KIND == 0) {
+                    hit = sphere_hit(static_cast<const DSphere*>(a.fam.shapes)[i], o, d, t);
+                } else if (KIND == 1) {
+                    hit = plane_hit(static_cast<const DPlane*>(a.fam.shapes)[i], o, d, t);
+                } else {
+                    const float4* tp = reinterpret_cast<const float4*>(static_cast<const DTriangle*>(a.fam.shapes) + i);
+                    const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+                    hit = triangle_hit(f3(v0.x, v0.y, v0.z), f3(v0.w, v1.x, v1.y), f3(v1.z, v1.w, v2.x), o, d, t);
+                }
+                if (hit && t < best_t) {
+                    best_t = t;
+                    best_i = i;
+                }
             }
         }
     }

@@ -37,10 +37,12 @@ constexpr uint32_t kHitKindShift = 30;
 constexpr uint32_t kHitPrimMask = (1u << kHitKindShift) - 1u;
 
 struct alignas(16) DNode {
-    float c0min[3];
-    float c0max[3];
-    float c1min[3];
-    float c1max[3];
+    // per axis: child 0 min, child 1 min, child 0 max, child 1 max — the two
+    // children side by side, so that each loaded register pair is one operand
+    // of the packed (two-wide) arithmetic of the slab test
+    float x[4];
+    float y[4];
+    float z[4];
     uint32_t ref0, ref1, pad0, pad1;
 };
 static_assert(sizeof(DNode) == 64, "branch record must be one 64-byte line");

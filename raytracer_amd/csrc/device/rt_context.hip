@@ -197,10 +197,13 @@ int build_family(RtContext* ctx, const char* name, const RtNode* nodes, uint32_t
         if (nd.b & RT_LEAF_BIT) continue;
         const uint32_t c[2] = {nd.a, nd.b};
         DNode& r = branches[branch_id[i]];
-        std::memcpy(r.c0min, nodes[c[0]].min, 12);
-        std::memcpy(r.c0max, nodes[c[0]].max, 12);
-        std::memcpy(r.c1min, nodes[c[1]].min, 12);
-        std::memcpy(r.c1max, nodes[c[1]].max, 12);
+        float* axis[3] = {r.x, r.y, r.z};
+        for (int k = 0; k < 3; ++k) {
+            axis[k][0] = nodes[c[0]].min[k];
+            axis[k][1] = nodes[c[1]].min[k];
+            axis[k][2] = nodes[c[0]].max[k];
+            axis[k][3] = nodes[c[1]].max[k];
+        }
         r.ref0 = ref_of(c[0]);
         r.ref1 = ref_of(c[1]);
         r.pad0 = r.pad1 = 0;
@@ -209,7 +212,7 @@ int build_family(RtContext* ctx, const char* name, const RtNode* nodes, uint32_t
             max_depth = std::max(max_depth, depth[c[k]]);
         }
     }
-    if (long_leaves.size() > kLeafFirstMask) return fail(ctx, RT_ERR_INVALID, std::string(name) + ": too many long leaves");
+    if (long_leaves.size() >= kLeafFirstMask) return fail(ctx, RT_ERR_INVALID, std::string(name) + ": too many long leaves");
     out.root_ref = ref_of(0);
     out.max_stack = max_depth + 2;
     // The kernels' cheaper exact division (div_by in kernels.h) is valid only when
@@ -218,7 +221,7 @@ int build_family(RtContext* ctx, const char* name, const RtNode* nodes, uint32_t
     // families) and extreme scenes keep the plain division.
     bool ordinary = true;
     for (const DNode& r : branches) {
-        const float* c = r.c0min;  // the twelve box floats are contiguous
+        const float* c = r.x;  // the twelve box floats are contiguous
         for (int k = 0; k < 12; ++k) {
             const float m = std::fabs(c[k]);
             if (!(m == 0.0f || (m >= 0x1p-60f && m < 0x1p59f))) ordinary = false;
