@@ -1,0 +1,89 @@
+"""The C ABI: headers compile as C and C++, the Python mirrors have the C
+layout, and the built libraries export every function the headers declare.
+No compute call is made, so this runs without a GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+from raytracer_amd import _ffi as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INCLUDE = os.path.join(ROOT, "include")
+
+
+def declared_functions(header):
+    text = open(os.path.join(INCLUDE, header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rth?_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_headers_compile_as_c_and_cpp(tmp_path):
+    src = tmp_path / "abi.c"
+    src.write_text('#include "rt_mi355.h"\n#include "rt_host.h"\n'
+                   "#include <stddef.h>\n"
+                   "_Static_assert(sizeof(RtNode) == 32, \"RtNode\");\n"
+                   "_Static_assert(sizeof(RtSphere) == 20, \"RtSphere\");\n"
+                   "_Static_assert(sizeof(RtPlane) == 28, \"RtPlane\");\n"
+                   "_Static_assert(sizeof(RtTriangle) == 52, \"RtTriangle\");\n"
+                   "_Static_assert(sizeof(RtMaterial) == 40 && offsetof(RtMaterial, tex_offset) == 32, \"RtMaterial\");\n"
+                   "_Static_assert(sizeof(RtHitRecord) == 12, \"RtHitRecord\");\n"
+                   f"_Static_assert(sizeof(RtSceneDesc) == {C.sizeof(F.RtSceneDesc)}, \"RtSceneDesc\");\n"
+                   f"_Static_assert(sizeof(RtRenderParams) == {C.sizeof(F.RtRenderParams)}, \"RtRenderParams\");\n"
+                   f"_Static_assert(offsetof(RtRenderParams, rng_seed) == {F.RtRenderParams.rng_seed.offset}, \"seed\");\n"
+                   f"_Static_assert(offsetof(RtRenderParams, tile_x) == {F.RtRenderParams.tile_x.offset}, \"tile\");\n"
+                   f"_Static_assert(sizeof(RtStats) == {C.sizeof(F.RtStats)}, \"RtStats\");\n"
+                   f"_Static_assert(offsetof(RtStats, trace_ms) == {F.RtStats.trace_ms.offset}, \"trace_ms\");\n"
+                   f"_Static_assert(RT_ABI_VERSION == {F.RT_ABI_VERSION}, \"version\");\n"
+                   "int main(void) { return 0; }\n")
+    subprocess.run(["gcc", "-std=c11", "-pedantic", "-Wall", "-Werror", "-I", INCLUDE, "-fsyntax-only", str(src)], check=True)
+    cpp = tmp_path / "abi.cpp"
+    cpp.write_text('#include "rt_mi355.h"\n#include "rt_host.h"\nint main() { return RT_OK; }\n')
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I", INCLUDE, "-fsyntax-only", str(cpp)], check=True)
+
+
+def test_device_library_exports_every_declared_function():
+    names = declared_functions("rt_mi355.h")
+    assert "rt_render" in names and "rt_upload_scene" in names and len(names) >= 13
+    lib = F.device_lib()  # loads, binds every symbol, checks the ABI version; no GPU call
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(F._DEVICE_SYMBOLS) == names
+    assert lib.rt_abi_version() == F.RT_ABI_VERSION
+
+
+def test_host_library_exports_every_declared_function():
+    names = [n for n in declared_functions("rt_host.h") if n.startswith("rth_")]
+    lib = F.host_lib()
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(F._HOST_SYMBOLS) == names
+
+
+def test_null_handles_are_errors_not_crashes():
+    lib = F.device_lib()
+    assert lib.rt_set_option(None, 1, 1) == -1
+    assert lib.rt_get_stats(None, None) == -1
+    assert lib.rt_upload_scene(None, None) == -1
+    assert lib.rt_last_error(None) == b"null context"
+    lib.rt_destroy(None)
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    monkeypatch.setattr(F, "LIB_DIR", str(tmp_path))
+    monkeypatch.setattr(F, "_device", None)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        F.device_lib()
+
+
+def test_product_package_never_touches_the_oracle():
+    # only tests/, bench.py's cpu_baseline and smoke() may use oracle/
+    pkg = os.path.join(ROOT, "raytracer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in text.lower(), os.path.join(dirpath, f)
