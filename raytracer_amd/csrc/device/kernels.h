@@ -113,20 +113,24 @@ __device__ __forceinline__ bool plane_hit(const DPlane& p, F3 o, F3 d, float& t)
     return t > kMinDistance;
 }
 
-// shapes.rs:232-259
+// shapes.rs:232-259.  The reference returns early after each failed test; here
+// every quantity is computed and the tests are combined at the end, which gives
+// the same answer (a failed earlier test makes the result false whatever the
+// later values, NaN or infinite, turn out to be) without branches inside a step
+// that other lanes of the wave are executing anyway.
 __device__ __forceinline__ bool triangle_hit(F3 a, F3 e1, F3 e2, F3 o, F3 d, float& t) {
     const F3 h = cross(d, e2);
     const float det = dot(e1, h);
-    if (fabsf(det) < 2e-6f) return false;
     const float inv = 1.0f / det;
     const F3 s = o - a;
     const float u = inv * dot(s, h);
-    if (!(u >= 0.0f && u <= 1.0f)) return false;
     const F3 q = cross(s, e1);
     const float v = inv * dot(d, q);
-    if (v < 0.0f || u + v > 1.0f) return false;
     t = inv * dot(e2, q);
-    return t > kMinDistance;
+    const bool ok_det = !(fabsf(det) < 2e-6f);
+    const bool ok_u = u >= 0.0f && u <= 1.0f;
+    const bool ok_v = !(v < 0.0f || u + v > 1.0f);
+    return ok_det & ok_u & ok_v & (t > kMinDistance);
 }
 
 // ------------------------------------------------------------------- trace
@@ -214,6 +218,7 @@ struct TraceArgs {
     uint32_t chunk_max;      // most rays a wave reserves from the queue per atomic
     int bounds_fast;         // every box coordinate is 0 or has magnitude in [2^-60, 2^59)
     unsigned long long* counters;  // [0] branch visits, [1] shape tests (COUNT only)
+    unsigned long long* wave_tallies;  // six diagnostic words, triangle family only (COUNT only)
 };
 
 template <int KIND, bool COUNT>
@@ -247,6 +252,8 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
     uint32_t item = kItemNone;              // node reference in hand (branch or leaf)
     uint32_t shape_cur = 0, shape_end = 0;  // shapes of the current leaf still to test
     unsigned long long n_branch = 0, n_tests = 0;
+    // wave-level tallies of how full the steps run (COUNT only)
+    uint32_t w_iters = 0, w_branch_runs = 0, w_branch_lanes = 0, w_shape_runs = 0, w_shape_lanes = 0, w_active_lanes = 0;
 
     for (;;) {
         if (!exhausted || pool_next != pool_end) {
@@ -291,6 +298,10 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
             continue;
         }
 
+        if (COUNT) {
+            ++w_iters;
+            w_active_lanes += __popcll(__ballot(active));
+        }
         // ---- pop: a lane with nothing in hand takes the first stack entry that
         //      survives the cull test of bvh.rs:252, or finishes its ray
         if (active && item == kItemNone && shape_cur == shape_end) {
@@ -316,6 +327,10 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
         {
             const uint32_t n_b = __popcll(__ballot(want_branch));
             const uint32_t n_s = __popcll(__ballot(shape_cur < shape_end));
+            if (COUNT && n_b > 0 && (n_b >= a.phase_min || n_b >= n_s)) {
+                ++w_branch_runs;
+                w_branch_lanes += n_b;
+            }
             if (n_b > 0 && (n_b >= a.phase_min || n_b >= n_s) && want_branch) {
                 const float4* np = reinterpret_cast<const float4*>(nodes + item);
                 const float4 qx = np[0], qy = np[1], qz = np[2];  // (c0min, c1min, c0max, c1max) per axis
@@ -374,6 +389,10 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
             const bool want_shape = shape_cur < shape_end;
             const uint32_t n_s = __popcll(__ballot(want_shape));
             const uint32_t n_b = __popcll(__ballot(item < kLeafBit));
+            if (COUNT && n_s > 0 && (n_s >= a.phase_min || n_s >= n_b)) {
+                ++w_shape_runs;
+                w_shape_lanes += n_s;
+            }
             if (n_s > 0 && (n_s >= a.phase_min || n_s >= n_b) && want_shape) {
                 const uint32_t i = shape_cur++;
                 float t;
@@ -397,6 +416,14 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
     if (COUNT) {
         atomicAdd(&a.counters[0], n_branch);
         atomicAdd(&a.counters[1], n_tests);
+        if (lane == 0 && a.wave_tallies) {
+            atomicAdd(&a.wave_tallies[0], static_cast<unsigned long long>(w_iters));
+            atomicAdd(&a.wave_tallies[1], static_cast<unsigned long long>(w_active_lanes));
+            atomicAdd(&a.wave_tallies[2], static_cast<unsigned long long>(w_branch_runs));
+            atomicAdd(&a.wave_tallies[3], static_cast<unsigned long long>(w_branch_lanes));
+            atomicAdd(&a.wave_tallies[4], static_cast<unsigned long long>(w_shape_runs));
+            atomicAdd(&a.wave_tallies[5], static_cast<unsigned long long>(w_shape_lanes));
+        }
     }
 }
 

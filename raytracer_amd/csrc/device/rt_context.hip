@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -77,11 +78,12 @@ struct RtContext {
     size_t events_used = 0;
 
     RtStats stats{};
+    unsigned long long tallies[6] = {};  // diagnostics: see k_trace
 };
 
 namespace {
 
-constexpr size_t kStatWords = 9;
+constexpr size_t kStatWords = 15;  // + six diagnostic tallies of the triangle traversal
 
 int fail(RtContext* ctx, int code, const std::string& msg) {
     if (ctx) ctx->error = msg;
@@ -397,6 +399,7 @@ int launch_trace(RtContext* ctx, const DQueue& q, const uint32_t* n_rays, uint32
         a.chunk_max = ctx->tune_chunk_max;
         a.bounds_fast = ctx->fam[kind].bounds_fast ? 1 : 0;
         a.counters = ctx->d_stats + 1 + 2 * kind;  // [branch visits, shape tests] of this family
+        a.wave_tallies = kind == RT_SHAPE_TRIANGLE ? ctx->d_stats + 9 : nullptr;
         const bool timed = ctx->opt_time && kind == RT_SHAPE_TRIANGLE;
         if (timed) {
             if (ctx->events_used + 2 > ctx->events.size()) {
@@ -441,6 +444,7 @@ int harvest(RtContext* ctx) {
     }
     ctx->stats.prim_tests[0] += h[7];
     ctx->stats.prim_tests[1] += h[8];
+    for (int k = 0; k < 6; ++k) ctx->tallies[k] += h[9 + k];
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof h, ctx->stream));
     return RT_OK;
 }
@@ -939,6 +943,10 @@ int rt_get_stats(RtContext* ctx, RtStats* out) {
 
 int rt_reset_stats(RtContext* ctx) {
     if (!ctx) return RT_ERR_INVALID;
+    if (std::getenv("RT_MI355_DEBUG_TALLIES"))
+        std::fprintf(stderr, "[rt_mi355] iters %llu active_lanes %llu branch_runs %llu branch_lanes %llu shape_runs %llu shape_lanes %llu\n",
+                     ctx->tallies[0], ctx->tallies[1], ctx->tallies[2], ctx->tallies[3], ctx->tallies[4], ctx->tallies[5]);
+    for (unsigned long long& t : ctx->tallies) t = 0;
     ctx->stats = RtStats{};
     return RT_OK;
 }
