@@ -249,6 +249,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
     int sp = 0;
     F3 o = f3(0, 0, 0), d = f3(0, 0, 0), rcp = f3(0, 0, 0);
     float best_t = kInfinity;
+    float prior_t = kInfinity;              // distance already recorded for this ray by an earlier family
     uint32_t item = kItemNone;              // node reference in hand (branch or leaf)
     uint32_t shape_cur = 0, shape_end = 0;  // shapes of the current leaf still to test
     unsigned long long n_branch = 0, n_tests = 0;
@@ -276,6 +277,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
                     ray = idx;
                     o = f3(a.q.origin[idx]);
                     d = f3(a.q.direction[idx]);
+                    prior_t = a.q.hit_t[idx];
                     best_t = kInfinity;
                     best_i = kHitNone;
                     sp = 0;
@@ -314,7 +316,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
             }
             if (item == kItemNone) {
                 // bvh.rs:300 + lib.rs:333: keep the earlier family on equal distance.
-                if (best_t < a.q.hit_t[ray]) {
+                if (best_t < prior_t) {
                     a.q.hit_t[ray] = best_t;
                     a.q.hit_id[ray] = (static_cast<uint32_t>(KIND) << kHitKindShift) | best_i;
                 }
