@@ -277,6 +277,14 @@ int rt_trace_primary(RtContext* ctx, const RtRenderParams* params,
 int rt_trace_rays(RtContext* ctx, const float* origins, const float* directions,
                   uint64_t n_rays, RtHitRecord* out);
 
+/* Device self-tests (no counterpart in the reference).  RT_SELF_TEST_DIVISION
+ * checks, on about `n_cases` operand pairs, that the traversal kernel's
+ * shared-reciprocal division returns exactly the bits of an IEEE division over
+ * the whole operand range it is used for; `failures` receives the number of
+ * differing quotients (0 on a correct build). */
+#define RT_SELF_TEST_DIVISION 1u
+int rt_self_test(RtContext* ctx, uint32_t which, uint64_t n_cases, uint64_t* failures);
+
 int rt_get_stats(RtContext* ctx, RtStats* out);
 int rt_reset_stats(RtContext* ctx);
 

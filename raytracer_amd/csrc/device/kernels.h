@@ -809,4 +809,40 @@ __global__ void k_expand_texels(const uint8_t* rgb8, uint32_t* out, unsigned lon
     out[i] = static_cast<uint32_t>(t[0]) | (static_cast<uint32_t>(t[1]) << 8) | (static_cast<uint32_t>(t[2]) << 16);
 }
 
+// Self-test of the shared-reciprocal division: compares div_by2 with `/` bit for
+// bit on pseudo-random operands drawn over the whole regime the traversal kernel
+// admits (|b| in [2^-30, 2), a == 0 or |a| in [2^-84, 2^60), either sign), plus
+// operands at the edges of that regime.  Counts quotients that differ (other
+// than in the sign of a zero).
+__global__ void k_selftest_division(unsigned long long seed, uint32_t per_thread, unsigned long long* mismatches) {
+    unsigned long long s = seed + (static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull;
+    auto next = [&]() {
+        s += kWy0;
+        const unsigned long long a = s, b = s ^ kWy1;
+        return (a * b) ^ __umul64hi(a, b);
+    };
+    unsigned long long bad = 0;
+    for (uint32_t i = 0; i < per_thread; ++i) {
+        const unsigned long long r0 = next(), r1 = next();
+        // b: exponent 97..127 (2^-30 .. 2^0), random mantissa and sign
+        const uint32_t be = 97u + static_cast<uint32_t>(r0 % 31u);
+        float b = __uint_as_float((static_cast<uint32_t>(r0 >> 63) << 31) | (be << 23) | (static_cast<uint32_t>(r0 >> 8) & 0x7FFFFFu));
+        // a: exponent 43..186 (2^-84 .. 2^59), random mantissa and sign; sometimes 0
+        const uint32_t ae = 43u + static_cast<uint32_t>(r1 % 144u);
+        float a0 = __uint_as_float((static_cast<uint32_t>(r1 >> 63) << 31) | (ae << 23) | (static_cast<uint32_t>(r1 >> 8) & 0x7FFFFFu));
+        float a1 = __uint_as_float(__float_as_uint(a0) ^ 0x00400001u);
+        if ((i & 1023u) == 0u) a0 = 0.0f;
+        if ((i & 1023u) == 1u) { a0 = 0x1p-84f; a1 = -0x1.fffffep59f; }
+        if ((i & 1023u) == 2u) { b = (i & 1024u) ? 0x1p-30f : -0x1.fffffep0f; }
+        if ((i & 1023u) == 3u) { b = __uint_as_float((__float_as_uint(b) & 0xFF800000u) | 0x7FFFFFu); }  // significand all ones
+        const float r = refine_rcp(b);
+        const v2f q = div_by2(v2f{a0, a1}, b, r);
+        const float w0 = a0 / b, w1 = a1 / b;
+        const bool ok0 = __float_as_uint(q.x) == __float_as_uint(w0) || (q.x == 0.0f && w0 == 0.0f);
+        const bool ok1 = __float_as_uint(q.y) == __float_as_uint(w1) || (q.y == 0.0f && w1 == 0.0f);
+        bad += (ok0 ? 0u : 1u) + (ok1 ? 0u : 1u);
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 }  // namespace rtd

@@ -935,6 +935,23 @@ int rt_trace_rays(RtContext* ctx, const float* origins, const float* directions,
     return download_hits(ctx, w.q[0], n, out);
 }
 
+int rt_self_test(RtContext* ctx, uint32_t which, uint64_t n_cases, uint64_t* failures) {
+    if (!ctx || !failures) return RT_ERR_INVALID;
+    if (which != RT_SELF_TEST_DIVISION) return fail(ctx, RT_ERR_INVALID, "unknown self test");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long), ctx->stream));
+    const uint32_t threads = 256u * 1024u;
+    const uint32_t per_thread = static_cast<uint32_t>(std::min<uint64_t>((n_cases / 2 + threads - 1) / threads, 1u << 20));
+    hipLaunchKernelGGL(k_selftest_division, dim3(threads / 256), dim3(256), 0, ctx->stream, 0x1234567ull, per_thread, ctx->d_stats);
+    HIP_TRY(ctx, hipGetLastError());
+    unsigned long long bad = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&bad, ctx->d_stats, sizeof bad, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long), ctx->stream));
+    *failures = bad;
+    return RT_OK;
+}
+
 int rt_get_stats(RtContext* ctx, RtStats* out) {
     if (!ctx || !out) return RT_ERR_INVALID;
     *out = ctx->stats;

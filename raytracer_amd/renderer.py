@@ -120,6 +120,13 @@ class Renderer:
                                             origins.shape[0], out.ctypes.data))
         return out
 
+    def self_test_division(self, n_cases: int = 1 << 28) -> int:
+        """Number of quotients (of about n_cases) on which the kernels' shared-
+        reciprocal division differs from IEEE division; 0 on a correct build."""
+        bad = F.u64(0)
+        self._check(self._lib.rt_self_test(self._ctx, 1, n_cases, C.byref(bad)))
+        return int(bad.value)
+
     # ------------------------------------------------------------------- stats
     def stats(self) -> dict:
         s = F.RtStats()

@@ -202,6 +202,34 @@ def test_resolve_matches_oracle(renderer):
                           O.resolve(s.params, sums, 4, True, 7, old.copy()))
 
 
+def test_shared_reciprocal_division_is_ieee_division(renderer):
+    # 2^29 operand pairs over the whole admitted regime, edges included: zero differences
+    assert renderer.self_test_division(1 << 29) == 0
+
+
+def test_extreme_coordinates_take_the_plain_division_path(renderer):
+    # coordinates outside the regime of the shared-reciprocal division (tiny, huge,
+    # and directions with tiny or zero components) must still match exactly
+    rng = np.random.default_rng(9)
+    for scale in (1e-25, 0.05, 3e4, 1e22):
+        v, f, _ = __import__("raytracer_amd").assets.grid_patch((-4 * scale, -4 * scale, 0), (8 * scale, 0, 0),
+                                                                   (0, 8 * scale, 0), 8, 8)
+        s = scenes.Scene.from_shapes(scenes.camera_params(w=16, h=16), triangles=scenes._triangles(v[f]),
+                                     materials=scenes._one_material())
+        renderer.upload(s)
+        o = (rng.uniform(-3, 3, (2000, 3)) * scale).astype(np.float32)
+        o[:, 2] = 5 * scale
+        d = rng.normal(size=(2000, 3)).astype(np.float32)
+        d[:, 2] = -np.abs(d[:, 2]) - 0.5
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        d[::5, 0] = 1e-35
+        d[::7, 1] = 0.0
+        gpu, cpu = renderer.trace_rays(o, d), O.trace_rays(s, o, d)
+        assert_hits_equal(gpu, cpu)
+        # at the extreme scales nothing can be hit (|det| < 2e-6, or overflow), identically on both sides
+        assert (gpu["kind"] == F.RT_SHAPE_TRIANGLE).any() == (1e-3 < scale < 1e6)
+
+
 def test_errors_are_reported_not_fatal(renderer):
     from raytracer_amd.renderer import Renderer, RtError
 
