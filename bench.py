@@ -98,6 +98,9 @@ def main() -> None:
     ap.add_argument("--bounces", type=int, default=60)
     ap.add_argument("--detail", type=int, default=4, help="tessellation of the generated room (4 = 2.9e5 triangles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="development aid: run all ranks on GPU 0 and reduce over gloo through host memory, to exercise "
+                         "the multi-rank control flow on a one-GPU machine (numbers are meaningless)")
     args = ap.parse_args()
 
     import torch
@@ -110,10 +113,15 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render loop has no CPU path")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     def barrier():
         if world > 1:
@@ -136,7 +144,12 @@ def main() -> None:
     rgb8 = np.zeros((args.height, args.width, 3), dtype=np.uint8)
 
     def reduce_to_root(t):
-        dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+        if args.rehearse_on_one_gpu:
+            host = t.cpu()
+            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+            t.copy_(host)
+        else:
+            dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
         torch.cuda.synchronize()
 
     def step():
@@ -169,7 +182,7 @@ def main() -> None:
     st = r.stats()
 
     agg = torch.tensor([dt, float(st["segments"]), float(st["paths"]), st["trace_ms"], float(st["trace_launches"])],
-                       dtype=torch.float64, device=device)
+                       dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else device)
     if world > 1:
         mx = agg.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
