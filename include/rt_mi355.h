@@ -217,7 +217,9 @@ typedef enum RtOption {
     /* Tuning knobs of the traversal kernel; results never depend on them. */
     RT_OPT_TRACE_LDS_SLOTS = 4, /* stack entries per ray kept in LDS (2..64)      */
     RT_OPT_TRACE_PHASE_MIN = 5, /* lanes that must wait for a step to run it      */
-    RT_OPT_TRACE_CHUNK = 6      /* rays a wave reserves per queue atomic          */
+    RT_OPT_TRACE_CHUNK = 6,     /* rays a wave reserves per queue atomic          */
+    RT_OPT_TRACE_SHARE = 7,     /* 0/1: deal a wave's pending triangle tests out to all its lanes */
+    RT_OPT_TRACE_PAIR_MIN = 8   /* pending tests that trigger such a shared step  */
 } RtOption;
 
 typedef struct RtContext RtContext;

@@ -22,6 +22,7 @@ RT_SHAPE_SPHERE, RT_SHAPE_PLANE, RT_SHAPE_TRIANGLE, RT_SHAPE_NONE = 0, 1, 2, 3
 RT_RNG_SUBSTREAM, RT_RNG_SERIAL = 0, 1
 RT_OPT_COUNT_TRAVERSAL, RT_OPT_TIME_KERNELS, RT_OPT_SAMPLES_IN_FLIGHT = 1, 2, 3
 RT_OPT_TRACE_LDS_SLOTS, RT_OPT_TRACE_PHASE_MIN, RT_OPT_TRACE_CHUNK = 4, 5, 6
+RT_OPT_TRACE_SHARE, RT_OPT_TRACE_PAIR_MIN = 7, 8
 
 f32, u32, u64, u8 = C.c_float, C.c_uint32, C.c_uint64, C.c_uint8
 

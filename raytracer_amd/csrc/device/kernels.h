@@ -143,7 +143,7 @@ __device__ __forceinline__ bool triangle_hit(F3 a, F3 e1, F3 e2, F3 o, F3 d, flo
 // cases — eleven instructions, four of which depend on b alone.  The slab test
 // divides twelve differences by the same three direction components per node,
 // so the reciprocal part is computed once per ray (refine_rcp) and each quotient
-// costs a multiply and four FMAs (div_by).  When no operand needs scaling this
+// costs a multiply and four FMAs (div_by2).  When no operand needs scaling this
 // is the very same operation sequence, hence the same bits.  The caller
 // guarantees that regime (see `fast` in k_trace): |b| in [2^-30, 2],
 // a == 0 or |a| in [2^-84, 2^60); anything else takes the plain `/`.
@@ -153,14 +153,6 @@ __device__ __forceinline__ float refine_rcp(float b) {
     const float e = __builtin_fmaf(-b, r0, 1.0f);
     return __builtin_fmaf(e, r0, r0);
 }
-__device__ __forceinline__ float div_by(float a, float b, float r) {
-    float q = a * r;
-    float e = __builtin_fmaf(-b, q, a);
-    q = __builtin_fmaf(e, r, q);
-    e = __builtin_fmaf(-b, q, a);
-    return __builtin_fmaf(e, r, q);
-}
-
 // Two quotients with a common divisor in one packed instruction stream
 // (v_pk_mul_f32 / v_pk_fma_f32 carry two binary32 operations per lane, each
 // rounded exactly like its scalar form).
@@ -216,14 +208,16 @@ struct TraceArgs {
     uint32_t lds_slots;      // stack entries per lane kept in LDS (dynamic LDS = lds_slots*64*8 bytes)
     uint32_t phase_min;      // a step runs for this many waiting lanes, or for the majority
     uint32_t chunk_max;      // most rays a wave reserves from the queue per atomic
+    uint32_t pair_min;       // SHARE: pending (ray, triangle) pairs that trigger a shared shape step
     int bounds_fast;         // every box coordinate is 0 or has magnitude in [2^-60, 2^59)
     unsigned long long* counters;  // [0] branch visits, [1] shape tests (COUNT only)
     unsigned long long* wave_tallies;  // six diagnostic words, triangle family only (COUNT only)
 };
 
-template <int KIND, bool COUNT>
+template <int KIND, bool COUNT, bool SHARE>
 __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint2 s_stack[];  // [lds_slots][64]
+    extern __shared__ __attribute__((aligned(16))) uint2 s_stack[];  // [lds_slots][64], then 64 result words (SHARE)
+    unsigned long long* const s_res = reinterpret_cast<unsigned long long*>(s_stack + a.lds_slots * kTraceBlock);
     const uint32_t lane = threadIdx.x;
     const uint32_t gtid = blockIdx.x * kTraceBlock + lane;
     const uint32_t n = *a.n_rays;
@@ -386,8 +380,64 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
             item = kItemNone;
         }
 
-        // ---- shape step: the next shape of the leaf, bvh.rs:288-295 (ascending, strict `<`)
-        {
+        // ---- shape step, bvh.rs:288-295
+        if (SHARE && KIND == 2) {
+            // All pending (ray, triangle) pairs of the wave are dealt out to its 64 lanes,
+            // so a leaf of k triangles costs its ray one step instead of k, and the step
+            // runs with full lanes.  The scan of a leaf keeps the smallest distance and, among
+            // equal distances, the lowest index, then replaces the closest hit on strict `<`:
+            // exactly what min over the key (distance bits, index) followed by one strict
+            // comparison gives (distances are positive, so their bit patterns order like
+            // the values).
+            const uint32_t c = shape_end - shape_cur;
+            uint32_t P = c;  // inclusive prefix sum of the pending counts
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t v = __shfl_up(P, off);
+                if (static_cast<int>(lane) >= off) P += v;
+            }
+            const uint32_t N = __builtin_amdgcn_readlane(P, 63);
+            const uint32_t n_s = __popcll(__ballot(c != 0));
+            const uint32_t n_b = __popcll(__ballot(item < kLeafBit));
+            if (N > 0 && (N >= a.pair_min || n_s >= n_b)) {  // wave-uniform
+                if (c) s_res[lane] = (static_cast<unsigned long long>(__float_as_uint(kInfinity)) << 32) | 0xFFFFFFFFull;
+                const uint32_t base = shape_cur - (P - c);  // pair j of this lane is triangle base + j
+                for (uint32_t cb = 0; cb < N; cb += 64) {
+                    const uint32_t j = cb + lane;
+                    uint32_t owner = 0;  // number of lanes whose pairs all come before j
+#pragma unroll
+                    for (uint32_t st = 32; st; st >>= 1) {
+                        const uint32_t pm = __shfl(P, owner + st - 1);
+                        if (pm <= j) owner += st;
+                    }
+                    owner = min(owner, 63u);
+                    const uint32_t tri = __shfl(base, owner) + j;
+                    const F3 oo = f3(__shfl(o.x, owner), __shfl(o.y, owner), __shfl(o.z, owner));
+                    const F3 dd = f3(__shfl(d.x, owner), __shfl(d.y, owner), __shfl(d.z, owner));
+                    if (COUNT) {
+                        ++w_shape_runs;
+                        w_shape_lanes += min(64u, N - cb);
+                    }
+                    if (j < N) {
+                        const float4* tp = reinterpret_cast<const float4*>(static_cast<const DTriangle*>(a.fam.shapes) + tri);
+                        const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
+                        float t;
+                        if (triangle_hit(f3(v0.x, v0.y, v0.z), f3(v0.w, v1.x, v1.y), f3(v1.z, v1.w, v2.x), oo, dd, t))
+                            atomicMin(&s_res[owner], (static_cast<unsigned long long>(__float_as_uint(t)) << 32) | tri);
+                    }
+                }
+                if (c) {
+                    const unsigned long long key = s_res[lane];
+                    const float t = __uint_as_float(static_cast<uint32_t>(key >> 32));
+                    if (t < best_t) {
+                        best_t = t;
+                        best_i = static_cast<uint32_t>(key);
+                    }
+                    shape_cur = shape_end;
+                }
+            }
+        } else {
+            // one shape per lane and step: ascending index, replace on strict `<`
             const bool want_shape = shape_cur < shape_end;
             const uint32_t n_s = __popcll(__ballot(want_shape));
             const uint32_t n_b = __popcll(__ballot(item < kLeafBit));

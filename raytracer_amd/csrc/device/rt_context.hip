@@ -71,7 +71,8 @@ struct RtContext {
     uint32_t trace_grid = 0;       // workgroups of the persistent traversal kernel
     uint32_t trace_grid_slots = 0; // the lds_slots value trace_grid was sized for
     uint32_t max_grid_threads = 0; // upper bound of trace_grid * 64 (sizes the spill area)
-    uint32_t tune_lds_slots = 8, tune_phase_min = 24, tune_chunk_max = 256;
+    uint32_t tune_lds_slots = 8, tune_phase_min = 24, tune_chunk_max = 256, tune_pair_min = 48;
+    bool tune_share = false;  // deal pending (ray, triangle) pairs out to all lanes
     bool opt_count = false, opt_time = false;
     uint64_t opt_samples_in_flight = 0;  // 0 = automatic
     std::vector<hipEvent_t> events;      // pairs around timed launches
@@ -360,19 +361,23 @@ unsigned long long* inline_counters(RtContext* ctx) { return ctx->opt_count ? ct
 
 template <int KIND>
 void launch_trace_kind(RtContext* ctx, const TraceArgs& a) {
-    const size_t lds = static_cast<size_t>(a.lds_slots) * kTraceBlock * sizeof(uint2);
-    if (ctx->opt_count)
-        hipLaunchKernelGGL((k_trace<KIND, true>), dim3(ctx->trace_grid), dim3(kTraceBlock), lds, ctx->stream, a);
-    else
-        hipLaunchKernelGGL((k_trace<KIND, false>), dim3(ctx->trace_grid), dim3(kTraceBlock), lds, ctx->stream, a);
+    const size_t lds = static_cast<size_t>(a.lds_slots) * kTraceBlock * sizeof(uint2) + kTraceBlock * sizeof(unsigned long long);
+    const bool share = ctx->tune_share && KIND == 2;
+    if (ctx->opt_count) {
+        if (share) hipLaunchKernelGGL((k_trace<KIND, true, true>), dim3(ctx->trace_grid), dim3(kTraceBlock), lds, ctx->stream, a);
+        else hipLaunchKernelGGL((k_trace<KIND, true, false>), dim3(ctx->trace_grid), dim3(kTraceBlock), lds, ctx->stream, a);
+    } else {
+        if (share) hipLaunchKernelGGL((k_trace<KIND, false, true>), dim3(ctx->trace_grid), dim3(kTraceBlock), lds, ctx->stream, a);
+        else hipLaunchKernelGGL((k_trace<KIND, false, false>), dim3(ctx->trace_grid), dim3(kTraceBlock), lds, ctx->stream, a);
+    }
 }
 
 // Size the persistent grid to what is resident at once for the current LDS use.
 void size_trace_grid(RtContext* ctx) {
     if (ctx->trace_grid && ctx->trace_grid_slots == ctx->tune_lds_slots) return;
     int per_cu = 0;
-    const size_t lds = static_cast<size_t>(ctx->tune_lds_slots) * kTraceBlock * sizeof(uint2);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<2, false>, kTraceBlock, lds) != hipSuccess || per_cu < 1)
+    const size_t lds = static_cast<size_t>(ctx->tune_lds_slots) * kTraceBlock * sizeof(uint2) + kTraceBlock * sizeof(unsigned long long);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<2, false, false>, kTraceBlock, lds) != hipSuccess || per_cu < 1)
         per_cu = 8;
     per_cu = std::min(per_cu, 32);
     ctx->trace_grid = static_cast<uint32_t>(ctx->n_cus) * static_cast<uint32_t>(per_cu);
@@ -397,6 +402,7 @@ int launch_trace(RtContext* ctx, const DQueue& q, const uint32_t* n_rays, uint32
         a.lds_slots = ctx->tune_lds_slots;
         a.phase_min = ctx->tune_phase_min;
         a.chunk_max = ctx->tune_chunk_max;
+        a.pair_min = ctx->tune_pair_min;
         a.bounds_fast = ctx->fam[kind].bounds_fast ? 1 : 0;
         a.counters = ctx->d_stats + 1 + 2 * kind;  // [branch visits, shape tests] of this family
         a.wave_tallies = kind == RT_SHAPE_TRIANGLE ? ctx->d_stats + 9 : nullptr;
@@ -624,6 +630,11 @@ int rt_set_option(RtContext* ctx, uint32_t option, uint64_t value) {
         case RT_OPT_TRACE_PHASE_MIN:
             if (value < 1 || value > 64) return fail(ctx, RT_ERR_INVALID, "phase threshold must be in 1..64");
             ctx->tune_phase_min = static_cast<uint32_t>(value);
+            return RT_OK;
+        case RT_OPT_TRACE_SHARE: ctx->tune_share = value != 0; return RT_OK;
+        case RT_OPT_TRACE_PAIR_MIN:
+            if (value < 1 || value > 4096) return fail(ctx, RT_ERR_INVALID, "pair threshold must be in 1..4096");
+            ctx->tune_pair_min = static_cast<uint32_t>(value);
             return RT_OK;
         case RT_OPT_TRACE_CHUNK:
             if (value < 64 || value > 4096 || value % 64) return fail(ctx, RT_ERR_INVALID, "chunk must be a multiple of 64 in 64..4096");

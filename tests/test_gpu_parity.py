@@ -202,6 +202,22 @@ def test_resolve_matches_oracle(renderer):
                           O.resolve(s.params, sums, 4, True, 7, old.copy()))
 
 
+@pytest.mark.parametrize("pair_min", [1, 48, 300])
+def test_shared_shape_step_gives_identical_results(renderer, asset_root, pair_min):
+    # the traversal variant that deals pending triangle tests out to all lanes
+    renderer.set_option(F.RT_OPT_TRACE_SHARE, 1)
+    renderer.set_option(F.RT_OPT_TRACE_PAIR_MIN, pair_min)
+    try:
+        check_scene(renderer, scenes.room(asset_root, w=64, h=36, spp=3, bounces=20))
+        check_scene(renderer, scenes.blob(asset_root, w=48, h=48, spp=2))
+        check_scene(renderer, scenes.stacked_duplicates(n=150, w=24, h=24))  # long leaf, several chunks, exact ties
+        check_scene(renderer, scenes.deep_chain(n=60, w=48, h=16))
+        check_scene(renderer, scenes.grid_wall(n=16, w=33, h=33))
+    finally:
+        renderer.set_option(F.RT_OPT_TRACE_SHARE, 0)
+        renderer.set_option(F.RT_OPT_TRACE_PAIR_MIN, 48)
+
+
 def test_shared_reciprocal_division_is_ieee_division(renderer):
     # 2^29 operand pairs over the whole admitted regime, edges included: zero differences
     assert renderer.self_test_division(1 << 29) == 0

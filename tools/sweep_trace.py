@@ -27,7 +27,7 @@ ap.add_argument("--bounces", type=int, default=60)
 ap.add_argument("--detail", type=int, default=4)
 ap.add_argument("knobs", nargs="*")
 args = ap.parse_args()
-knobs = {"slots": [8], "phase": [24], "chunk": [256], "inflight": [0]}
+knobs = {"slots": [8], "phase": [24], "chunk": [256], "inflight": [0], "share": [0], "pairs": [48]}
 for k in args.knobs:
     name, vals = k.split("=")
     knobs[name] = [int(v) for v in vals.split(",")]
@@ -36,7 +36,7 @@ scene = bench.load_scene(args)
 r = Renderer(0)
 r.upload(scene)
 r.set_option(F.RT_OPT_TIME_KERNELS, 1)
-combos = list(itertools.product(knobs["slots"], knobs["phase"], knobs["chunk"], knobs["inflight"]))
+combos = list(itertools.product(knobs["slots"], knobs["phase"], knobs["chunk"], knobs["inflight"], knobs["share"], knobs["pairs"]))
 res = {c: [] for c in combos}
 r.render_sums(scene.params, 0, 1)  # warm-up
 for rnd in range(args.rounds):
@@ -45,15 +45,17 @@ for rnd in range(args.rounds):
         r.set_option(F.RT_OPT_TRACE_PHASE_MIN, c[1])
         r.set_option(F.RT_OPT_TRACE_CHUNK, c[2])
         r.set_option(F.RT_OPT_SAMPLES_IN_FLIGHT, c[3])
+        r.set_option(F.RT_OPT_TRACE_SHARE, c[4])
+        r.set_option(F.RT_OPT_TRACE_PAIR_MIN, c[5])
         r.reset_stats()
         t0 = time.perf_counter()
         r.render_sums(scene.params, 100 * rnd, args.spp)
         dt = time.perf_counter() - t0
         s = r.stats()
         res[c].append((s["trace_ms"], dt * 1e3, s["segments"]))
-print("slots phase chunk inflight | trace_ms  total_ms  Mrays/s")
+print("slots phase chunk inflight share pairs | trace_ms  total_ms  Mrays/s")
 for c in combos:
     tr = statistics.median(x[0] for x in res[c])
     tot = statistics.median(x[1] for x in res[c])
     seg = res[c][0][2]
-    print(f"{c[0]:5d} {c[1]:5d} {c[2]:5d} {c[3]:8d} | {tr:8.1f}  {tot:8.1f}  {seg / tot / 1e3:8.1f}", flush=True)
+    print(f"{c[0]:5d} {c[1]:5d} {c[2]:5d} {c[3]:8d} {c[4]:5d} {c[5]:5d} | {tr:8.1f}  {tot:8.1f}  {seg / tot / 1e3:8.1f}", flush=True)
