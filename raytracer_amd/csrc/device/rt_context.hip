@@ -71,8 +71,8 @@ struct RtContext {
     uint32_t trace_grid = 0;       // workgroups of the persistent traversal kernel
     uint32_t trace_grid_slots = 0; // the lds_slots value trace_grid was sized for
     uint32_t max_grid_threads = 0; // upper bound of trace_grid * 64 (sizes the spill area)
-    uint32_t tune_lds_slots = 8, tune_phase_min = 24, tune_chunk_max = 256, tune_pair_min = 48;
-    bool tune_share = false;  // deal pending (ray, triangle) pairs out to all lanes
+    uint32_t tune_lds_slots = 8, tune_phase_min = 24, tune_chunk_max = 256, tune_pair_min = 128;
+    bool tune_share = true;  // deal pending (ray, triangle) pairs out to all lanes
     bool opt_count = false, opt_time = false;
     uint64_t opt_samples_in_flight = 0;  // 0 = automatic
     std::vector<hipEvent_t> events;      // pairs around timed launches
