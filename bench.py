@@ -38,6 +38,21 @@ from raytracer_amd.scene import Scene  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, spec
 
 
+def recorded_traffic(args):
+    """Memory-side bytes per launch of the traversal kernel, from the hardware-
+    counter passes recorded in profiles/ (tools/pmc_profile.sh + tools/pmc_traffic.py:
+    FETCH_SIZE doubled as measured for 128-B requests on gfx950, plus WRITE_SIZE).
+    Counters cannot be collected inside a timed run, so the figure is the one
+    recorded for this same workload, or None when the workload differs."""
+    if (args.width, args.height, args.spp, args.bounces, args.detail) != (1920, 1080, 256, 60, 4):
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            return float(json.load(f)["bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def load_scene(args) -> Scene:
     """Generate (once) and parse the room scene.  The parsed arrays are cached
     next to the generated OBJ so that several ranks do not each rebuild the BVH."""
@@ -200,6 +215,7 @@ def main() -> None:
         my_trace_ms, my_launches, my_segments = st["trace_ms"], max(st["trace_launches"], 1), st["segments"]
         achieved = trace_bytes_per_ray * my_segments / (my_trace_ms / 1e3) / 1e9 if my_trace_ms > 0 else 0.0
         rays_per_s = segments / dt
+        traffic = recorded_traffic(args)
         out = {
             "metric": "Mrays/s (all bounces) breakfast-room 1080p",
             "value": round(rays_per_s / 1e6, 3),
@@ -229,7 +245,9 @@ def main() -> None:
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_unit": "bytes per launch (memory-side counters, recorded profile)",
+                "algorithmic_bytes_per_launch": round(trace_bytes_per_ray * my_segments / my_launches),
                 "bytes_per_ray": round(trace_bytes_per_ray, 1),
                 "avg_launch_ms": round(my_trace_ms / my_launches, 4),
                 "launches": int(my_launches),

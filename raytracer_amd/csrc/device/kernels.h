@@ -195,6 +195,58 @@ __device__ __forceinline__ bool magnitude_in(float v, float lo, float hi) {
 // (mod 64), whatever slot it is at, so divergent stack depths never conflict.
 // Deeper entries overflow to a private strip of global memory.
 
+// Streaming accesses to the path queues: every element is touched once per
+// kernel and the queues are far larger than the caches, so they are marked
+// non-temporal to leave cache space to the scene data (nodes, surface records,
+// texels), which is re-read.
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t nt_u2 __attribute__((ext_vector_type(2)));
+__device__ inline float4 stream_load(const float4* p) {
+    const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ inline uint2 stream_load(const uint2* p) {
+    const nt_u2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u2*>(p));
+    return make_uint2(v.x, v.y);
+}
+__device__ inline uint32_t stream_load(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+__device__ inline float stream_load(const float* p) { return __builtin_nontemporal_load(p); }
+__device__ inline void stream_store(float4* p, float4 v) {
+    __builtin_nontemporal_store(nt_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_f4*>(p));
+}
+__device__ inline void stream_store(uint2* p, uint2 v) {
+    __builtin_nontemporal_store(nt_u2{v.x, v.y}, reinterpret_cast<nt_u2*>(p));
+}
+__device__ inline void stream_store(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+__device__ inline void stream_store(float* p, float v) { __builtin_nontemporal_store(v, p); }
+
+// Inclusive scans over the 64 lanes of a wave with data-parallel-primitive moves
+// (row shifts inside each row of 16 lanes, then the last lane of row 0/2 and of
+// lane 31 broadcast forward), which cost a few VALU cycles each instead of a
+// trip through the LDS crossbar.  Every lane of the wave must be executing.
+template <int CTRL, int ROW_MASK>
+__device__ inline uint32_t dpp_or_zero(uint32_t v) {
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ inline uint32_t wave_scan_add(uint32_t v) {
+    v += dpp_or_zero<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_or_zero<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_or_zero<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_or_zero<0x118, 0xf>(v);  // row_shr:8
+    v += dpp_or_zero<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_or_zero<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ inline uint32_t wave_scan_max(uint32_t v) {
+    v = max(v, dpp_or_zero<0x111, 0xf>(v));
+    v = max(v, dpp_or_zero<0x112, 0xf>(v));
+    v = max(v, dpp_or_zero<0x114, 0xf>(v));
+    v = max(v, dpp_or_zero<0x118, 0xf>(v));
+    v = max(v, dpp_or_zero<0x142, 0xa>(v));
+    v = max(v, dpp_or_zero<0x143, 0xc>(v));
+    return v;
+}
+
 constexpr int kTraceBlock = 64;
 constexpr uint32_t kItemNone = 0xFFFFFFFFu;
 
@@ -216,8 +268,9 @@ struct TraceArgs {
 
 template <int KIND, bool COUNT, bool SHARE>
 __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint2 s_stack[];  // [lds_slots][64], then 64 result words (SHARE)
+    extern __shared__ __attribute__((aligned(16))) uint2 s_stack[];  // [lds_slots][64]; SHARE: + 64 result keys + 64 marks
     unsigned long long* const s_res = reinterpret_cast<unsigned long long*>(s_stack + a.lds_slots * kTraceBlock);
+    uint32_t* const s_mark = reinterpret_cast<uint32_t*>(s_res + kTraceBlock);
     const uint32_t lane = threadIdx.x;
     const uint32_t gtid = blockIdx.x * kTraceBlock + lane;
     const uint32_t n = *a.n_rays;
@@ -390,12 +443,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
             // comparison gives (distances are positive, so their bit patterns order like
             // the values).
             const uint32_t c = shape_end - shape_cur;
-            uint32_t P = c;  // inclusive prefix sum of the pending counts
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t v = __shfl_up(P, off);
-                if (static_cast<int>(lane) >= off) P += v;
-            }
+            const uint32_t P = wave_scan_add(c);  // inclusive prefix sum of the pending counts
             const uint32_t N = __builtin_amdgcn_readlane(P, 63);
             const uint32_t n_s = __popcll(__ballot(c != 0));
             const uint32_t n_b = __popcll(__ballot(item < kLeafBit));
@@ -404,13 +452,19 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
                 const uint32_t base = shape_cur - (P - c);  // pair j of this lane is triangle base + j
                 for (uint32_t cb = 0; cb < N; cb += 64) {
                     const uint32_t j = cb + lane;
-                    uint32_t owner = 0;  // number of lanes whose pairs all come before j
-#pragma unroll
-                    for (uint32_t st = 32; st; st >>= 1) {
-                        const uint32_t pm = __shfl(P, owner + st - 1);
-                        if (pm <= j) owner += st;
-                    }
-                    owner = min(owner, 63u);
+                    // The lane that owns pair j: every lane whose run of pairs begins inside
+                    // this group of 64 (or covers its first pair) marks that position with its
+                    // number + 1; a running maximum then carries each mark forward over the run
+                    // (runs are laid out in lane order, so later marks are larger).
+                    // (atomic accesses: the word a lane reads back was written by another lane,
+                    // which plain loads and stores would let the compiler assume away)
+                    __hip_atomic_store(&s_mark[lane], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    if (c && P > cb && P - c < cb + 64)
+                        __hip_atomic_store(&s_mark[P - c > cb ? P - c - cb : 0], lane + 1, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __builtin_amdgcn_wave_barrier();
+                    const uint32_t mark = __hip_atomic_load(&s_mark[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    const uint32_t owner = min(wave_scan_max(mark) - 1u, 63u);
                     const uint32_t tri = __shfl(base, owner) + j;
                     const F3 oo = f3(__shfl(o.x, owner), __shfl(o.y, owner), __shfl(o.z, owner));
                     const F3 dd = f3(__shfl(d.x, owner), __shfl(d.y, owner), __shfl(d.z, owner));
@@ -418,7 +472,7 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
                         ++w_shape_runs;
                         w_shape_lanes += min(64u, N - cb);
                     }
-                    if (j < N) {
+                    if (j < N && tri < a.fam.n_shapes) {  // the second test only keeps a logic error from reading outside the table
                         const float4* tp = reinterpret_cast<const float4*>(static_cast<const DTriangle*>(a.fam.shapes) + tri);
                         const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
                         float t;
@@ -661,10 +715,10 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
         unsigned long long rng = 0;
         uint32_t slot = 0;
         if (i < n) {
-            const F3 o = f3(a.cur.origin[i]), d = f3(a.cur.direction[i]);
-            thr = f3(a.cur.throughput[i]);
-            slot = a.cur.slot[i];
-            const uint32_t id = a.cur.hit_id[i];
+            const F3 o = f3(stream_load(&a.cur.origin[i])), d = f3(stream_load(&a.cur.direction[i]));
+            thr = f3(stream_load(&a.cur.throughput[i]));
+            slot = stream_load(&a.cur.slot[i]);
+            const uint32_t id = stream_load(&a.cur.hit_id[i]);
             if (id == kHitNone) {
                 // lib.rs:337-345
                 const float s = 0.5f * (d.y + 1.0f);
@@ -673,9 +727,9 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
                 a.result[slot] = make_float4(thr.x, thr.y, thr.z, 0.0f);
             } else {
                 ++my_hits;
-                const uint2 rs = a.cur.rng[i];
+                const uint2 rs = stream_load(&a.cur.rng[i]);
                 rng = (static_cast<unsigned long long>(rs.y) << 32) | rs.x;
-                const float t = a.cur.hit_t[i];
+                const float t = stream_load(&a.cur.hit_t[i]);
                 const uint32_t kind = id >> kHitKindShift, prim = id & kHitPrimMask;
                 const F3 p = o + d * t;  // bvh.rs:303
                 F3 normal;
@@ -787,16 +841,16 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
         if (alive) {
             uint32_t dst = s_block_base + __popcll(live & ((1ull << lane) - 1ull));
             for (uint32_t k = 0; k < wave; ++k) dst += s_wave_live[k];
-            a.next.origin[dst] = make_float4(no.x, no.y, no.z, 0.0f);
-            a.next.direction[dst] = make_float4(nd.x, nd.y, nd.z, 0.0f);
-            a.next.throughput[dst] = make_float4(thr.x, thr.y, thr.z, 0.0f);
-            a.next.rng[dst] = make_uint2(static_cast<uint32_t>(rng), static_cast<uint32_t>(rng >> 32));
-            a.next.slot[dst] = slot;
+            stream_store(&a.next.origin[dst], make_float4(no.x, no.y, no.z, 0.0f));
+            stream_store(&a.next.direction[dst], make_float4(nd.x, nd.y, nd.z, 0.0f));
+            stream_store(&a.next.throughput[dst], make_float4(thr.x, thr.y, thr.z, 0.0f));
+            stream_store(&a.next.rng[dst], make_uint2(static_cast<uint32_t>(rng), static_cast<uint32_t>(rng >> 32)));
+            stream_store(&a.next.slot[dst], slot);
             float ht;
             uint32_t hid;
             seed_hit(a.scene, no, nd, ht, hid, a.test_counters);
-            a.next.hit_t[dst] = ht;
-            a.next.hit_id[dst] = hid;
+            stream_store(&a.next.hit_t[dst], ht);
+            stream_store(&a.next.hit_id[dst], hid);
         }
         __syncthreads();  // s_wave_live / s_block_base are rewritten next round
     }

@@ -71,7 +71,7 @@ struct RtContext {
     uint32_t trace_grid = 0;       // workgroups of the persistent traversal kernel
     uint32_t trace_grid_slots = 0; // the lds_slots value trace_grid was sized for
     uint32_t max_grid_threads = 0; // upper bound of trace_grid * 64 (sizes the spill area)
-    uint32_t tune_lds_slots = 8, tune_phase_min = 24, tune_chunk_max = 256, tune_pair_min = 128;
+    uint32_t tune_lds_slots = 8, tune_phase_min = 24, tune_chunk_max = 256, tune_pair_min = 384;
     bool tune_share = true;  // deal pending (ray, triangle) pairs out to all lanes
     bool opt_count = false, opt_time = false;
     uint64_t opt_samples_in_flight = 0;  // 0 = automatic
@@ -361,7 +361,7 @@ unsigned long long* inline_counters(RtContext* ctx) { return ctx->opt_count ? ct
 
 template <int KIND>
 void launch_trace_kind(RtContext* ctx, const TraceArgs& a) {
-    const size_t lds = static_cast<size_t>(a.lds_slots) * kTraceBlock * sizeof(uint2) + kTraceBlock * sizeof(unsigned long long);
+    const size_t lds = static_cast<size_t>(a.lds_slots) * kTraceBlock * sizeof(uint2) + kTraceBlock * (sizeof(unsigned long long) + sizeof(uint32_t));
     const bool share = ctx->tune_share && KIND == 2;
     if (ctx->opt_count) {
         if (share) hipLaunchKernelGGL((k_trace<KIND, true, true>), dim3(ctx->trace_grid), dim3(kTraceBlock), lds, ctx->stream, a);
@@ -376,7 +376,7 @@ void launch_trace_kind(RtContext* ctx, const TraceArgs& a) {
 void size_trace_grid(RtContext* ctx) {
     if (ctx->trace_grid && ctx->trace_grid_slots == ctx->tune_lds_slots) return;
     int per_cu = 0;
-    const size_t lds = static_cast<size_t>(ctx->tune_lds_slots) * kTraceBlock * sizeof(uint2) + kTraceBlock * sizeof(unsigned long long);
+    const size_t lds = static_cast<size_t>(ctx->tune_lds_slots) * kTraceBlock * sizeof(uint2) + kTraceBlock * (sizeof(unsigned long long) + sizeof(uint32_t));
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<2, false, false>, kTraceBlock, lds) != hipSuccess || per_cu < 1)
         per_cu = 8;
     per_cu = std::min(per_cu, 32);

@@ -27,7 +27,7 @@ ap.add_argument("--bounces", type=int, default=60)
 ap.add_argument("--detail", type=int, default=4)
 ap.add_argument("knobs", nargs="*")
 args = ap.parse_args()
-knobs = {"slots": [8], "phase": [24], "chunk": [256], "inflight": [0], "share": [0], "pairs": [48]}
+knobs = {"slots": [8], "phase": [24], "chunk": [256], "inflight": [0], "share": [1], "pairs": [384]}
 for k in args.knobs:
     name, vals = k.split("=")
     knobs[name] = [int(v) for v in vals.split(",")]
