@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -26,6 +27,7 @@ struct Family {
     void* shapes = nullptr;
     uint32_t root_ref = kLeafBit;  // empty leaf
     uint32_t n_shapes = 0;
+    uint32_t n_branches = 0;  // branch records
     uint32_t max_stack = 1;
     bool bounds_fast = false;  // all box coordinates are 0 or of magnitude in [2^-60, 2^59)
 };
@@ -68,9 +70,8 @@ struct RtContext {
     uint32_t* h_pinned = nullptr;           // small pinned read-back area
     size_t h_pinned_words = 0;
 
-    uint32_t trace_grid = 0;       // workgroups of the persistent traversal kernel
-    uint32_t trace_grid_slots = 0; // the lds_slots value trace_grid was sized for
-    uint32_t max_grid_threads = 0; // upper bound of trace_grid * 64 (sizes the spill area)
+    std::map<std::pair<const void*, size_t>, int> trace_occupancy;  // (kernel, LDS bytes) -> workgroups per CU
+    uint32_t max_grid_threads = 0; // upper bound of the traversal grid's threads (sizes the spill area)
     uint32_t tune_lds_slots = 8, tune_phase_min = 24, tune_chunk_max = 256, tune_pair_min = 384;
     bool tune_share = true;  // deal pending (ray, triangle) pairs out to all lanes
     bool opt_count = false, opt_time = false;
@@ -94,9 +95,11 @@ int fail(RtContext* ctx, int code, const std::string& msg) {
 #define HIP_TRY(ctx, expr)                                                                   \
     do {                                                                                     \
         hipError_t e_ = (expr);                                                              \
-        if (e_ != hipSuccess)                                                                \
+        if (e_ != hipSuccess) {                                                              \
+            (void)hipGetLastError(); /* do not let it resurface at a later check */          \
             return fail(ctx, e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP,            \
                         std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+        }                                                                                    \
     } while (0)
 
 template <class T>
@@ -159,6 +162,7 @@ int build_family(RtContext* ctx, const char* name, const RtNode* nodes, uint32_t
     branches.clear();
     long_leaves.clear();
     out.n_shapes = n_shapes;
+    out.n_branches = 0;
     out.root_ref = kLeafBit;
     out.max_stack = 1;
     out.bounds_fast = false;
@@ -170,7 +174,6 @@ int build_family(RtContext* ctx, const char* name, const RtNode* nodes, uint32_t
     if (n_shapes > kLeafFirstMask) return fail(ctx, RT_ERR_INVALID, std::string(name) + ": too many shapes");
 
     std::vector<uint32_t> branch_id(n_nodes, 0xFFFFFFFFu), depth(n_nodes, 0);
-    uint32_t n_branch = 0;
     for (uint32_t i = 0; i < n_nodes; ++i) {
         const RtNode& nd = nodes[i];
         if (nd.b & RT_LEAF_BIT) {
@@ -182,7 +185,23 @@ int build_family(RtContext* ctx, const char* name, const RtNode* nodes, uint32_t
             // that also rules out cycles
             if (nd.a <= i || nd.b <= i || nd.a >= n_nodes || nd.b >= n_nodes)
                 return fail(ctx, RT_ERR_INVALID, std::string(name) + ": bad child index");
+        }
+    }
+    // Branch records are numbered breadth-first from the root, so that the top of
+    // the tree, which every ray walks, is one contiguous run at the start of the
+    // array.  Nodes the root cannot reach get no record.
+    uint32_t n_branch = 0;
+    {
+        std::vector<uint32_t> order;
+        order.reserve(n_nodes);
+        if (!(nodes[0].b & RT_LEAF_BIT)) order.push_back(0);
+        for (size_t head = 0; head < order.size(); ++head) {
+            const uint32_t i = order[head];
+            if (branch_id[i] != 0xFFFFFFFFu) continue;  // a node with two parents keeps its first number
             branch_id[i] = n_branch++;
+            const uint32_t c[2] = {nodes[i].a, nodes[i].b};
+            for (int k = 0; k < 2; ++k)
+                if (!(nodes[c[k]].b & RT_LEAF_BIT)) order.push_back(c[k]);
         }
     }
     auto ref_of = [&](uint32_t i) -> uint32_t {
@@ -194,10 +213,11 @@ int build_family(RtContext* ctx, const char* name, const RtNode* nodes, uint32_t
         return kLeafBit | (kLeafLong << kLeafCountShift) | static_cast<uint32_t>(long_leaves.size() - 1);
     };
     branches.resize(n_branch);
+    out.n_branches = n_branch;
     uint32_t max_depth = 0;
     for (uint32_t i = 0; i < n_nodes; ++i) {
         const RtNode& nd = nodes[i];
-        if (nd.b & RT_LEAF_BIT) continue;
+        if ((nd.b & RT_LEAF_BIT) || branch_id[i] == 0xFFFFFFFFu) continue;
         const uint32_t c[2] = {nd.a, nd.b};
         DNode& r = branches[branch_id[i]];
         float* axis[3] = {r.x, r.y, r.z};
@@ -359,36 +379,44 @@ DScene device_scene(const RtContext* ctx) {
 // counting is on.  d_stats: [0] hits, then {branch visits, shape tests} x 3.
 unsigned long long* inline_counters(RtContext* ctx) { return ctx->opt_count ? ctx->d_inline_tests : nullptr; }
 
-template <int KIND>
-void launch_trace_kind(RtContext* ctx, const TraceArgs& a) {
-    const size_t lds = static_cast<size_t>(a.lds_slots) * kTraceBlock * sizeof(uint2) + kTraceBlock * (sizeof(unsigned long long) + sizeof(uint32_t));
-    const bool share = ctx->tune_share && KIND == 2;
-    if (ctx->opt_count) {
-        if (share) hipLaunchKernelGGL((k_trace<KIND, true, true>), dim3(ctx->trace_grid), dim3(kTraceBlock), lds, ctx->stream, a);
-        else hipLaunchKernelGGL((k_trace<KIND, true, false>), dim3(ctx->trace_grid), dim3(kTraceBlock), lds, ctx->stream, a);
-    } else {
-        if (share) hipLaunchKernelGGL((k_trace<KIND, false, true>), dim3(ctx->trace_grid), dim3(kTraceBlock), lds, ctx->stream, a);
-        else hipLaunchKernelGGL((k_trace<KIND, false, false>), dim3(ctx->trace_grid), dim3(kTraceBlock), lds, ctx->stream, a);
+// Launch one traversal kernel variant over a grid that is exactly what the
+// device keeps resident for its register and LDS use (the kernel is persistent:
+// its waves loop until the queue is drained).
+template <int KIND, bool COUNT, bool SHARE>
+int launch_trace_variant(RtContext* ctx, TraceArgs a) {
+    const void* fn = reinterpret_cast<const void*>(&k_trace<KIND, COUNT, SHARE>);
+    // per wave: lds_slots stack entries per lane, then 64 result keys and 64 marks (SHARE)
+    const size_t lds = static_cast<size_t>(a.lds_slots) * kTraceBlock * sizeof(uint2) +
+                       kTraceBlock * (sizeof(unsigned long long) + sizeof(uint32_t));
+    const auto key = std::make_pair(fn, lds);
+    auto it = ctx->trace_occupancy.find(key);
+    if (it == ctx->trace_occupancy.end()) {
+        int per_cu = 0;
+        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kTraceBlock, lds));
+        if (per_cu < 1) return fail(ctx, RT_ERR_INVALID, "traversal workgroup does not fit a compute unit");
+        it = ctx->trace_occupancy.emplace(key, std::min(per_cu, 32)).first;
     }
+    const uint32_t grid = static_cast<uint32_t>(ctx->n_cus) * static_cast<uint32_t>(it->second);
+    a.spill_stride = grid * static_cast<uint32_t>(kTraceBlock);
+    if (a.spill_stride > ctx->max_grid_threads) return fail(ctx, RT_ERR_INVALID, "traversal grid larger than the stack overflow area");
+    hipLaunchKernelGGL((k_trace<KIND, COUNT, SHARE>), dim3(grid), dim3(kTraceBlock), lds, ctx->stream, a);
+    return RT_OK;
 }
 
-// Size the persistent grid to what is resident at once for the current LDS use.
-void size_trace_grid(RtContext* ctx) {
-    if (ctx->trace_grid && ctx->trace_grid_slots == ctx->tune_lds_slots) return;
-    int per_cu = 0;
-    const size_t lds = static_cast<size_t>(ctx->tune_lds_slots) * kTraceBlock * sizeof(uint2) + kTraceBlock * (sizeof(unsigned long long) + sizeof(uint32_t));
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_trace<2, false, false>, kTraceBlock, lds) != hipSuccess || per_cu < 1)
-        per_cu = 8;
-    per_cu = std::min(per_cu, 32);
-    ctx->trace_grid = static_cast<uint32_t>(ctx->n_cus) * static_cast<uint32_t>(per_cu);
-    ctx->trace_grid_slots = ctx->tune_lds_slots;
+template <int KIND>
+int launch_trace_kind(RtContext* ctx, const TraceArgs& a) {
+    if constexpr (KIND == 2) {
+        // the triangle family can deal its pending tests out to all lanes
+        if (ctx->tune_share)
+            return ctx->opt_count ? launch_trace_variant<2, true, true>(ctx, a) : launch_trace_variant<2, false, true>(ctx, a);
+    }
+    return ctx->opt_count ? launch_trace_variant<KIND, true, false>(ctx, a) : launch_trace_variant<KIND, false, false>(ctx, a);
 }
 
 // Nearest hit of every ray in `q` over the three families, in the reference's
 // order (lib.rs:314-333).  `cursors` points at three zeroed words.
 int launch_trace(RtContext* ctx, const DQueue& q, const uint32_t* n_rays, uint32_t* cursors) {
     const DScene sc = device_scene(ctx);
-    size_trace_grid(ctx);
     for (int kind = 0; kind < 3; ++kind) {
         if (ctx->fam[kind].n_shapes == 0) continue;  // an empty family can never be hit
         if (kind < 2 && ctx->inline_count[kind]) continue;  // already scanned when the ray was created
@@ -398,7 +426,6 @@ int launch_trace(RtContext* ctx, const DQueue& q, const uint32_t* n_rays, uint32
         a.n_rays = n_rays;
         a.cursor = cursors + kind;
         a.spill = ctx->ws.spill;
-        a.spill_stride = ctx->trace_grid * kTraceBlock;
         a.lds_slots = ctx->tune_lds_slots;
         a.phase_min = ctx->tune_phase_min;
         a.chunk_max = ctx->tune_chunk_max;
@@ -417,9 +444,8 @@ int launch_trace(RtContext* ctx, const DQueue& q, const uint32_t* n_rays, uint32
             }
             HIP_TRY(ctx, hipEventRecord(ctx->events[ctx->events_used], ctx->stream));
         }
-        if (kind == 0) launch_trace_kind<0>(ctx, a);
-        else if (kind == 1) launch_trace_kind<1>(ctx, a);
-        else launch_trace_kind<2>(ctx, a);
+        const int rc = kind == 0 ? launch_trace_kind<0>(ctx, a) : kind == 1 ? launch_trace_kind<1>(ctx, a) : launch_trace_kind<2>(ctx, a);
+        if (rc) return rc;
         HIP_TRY(ctx, hipGetLastError());
         if (timed) {
             HIP_TRY(ctx, hipEventRecord(ctx->events[ctx->events_used + 1], ctx->stream));

@@ -202,20 +202,29 @@ def test_resolve_matches_oracle(renderer):
                           O.resolve(s.params, sums, 4, True, 7, old.copy()))
 
 
-@pytest.mark.parametrize("pair_min", [1, 48, 300])
-def test_shared_shape_step_gives_identical_results(renderer, asset_root, pair_min):
-    # the traversal variant that deals pending triangle tests out to all lanes
-    renderer.set_option(F.RT_OPT_TRACE_SHARE, 1)
+TRACE_DEFAULTS = {F.RT_OPT_TRACE_SHARE: 1, F.RT_OPT_TRACE_PAIR_MIN: 384, F.RT_OPT_TRACE_LDS_SLOTS: 8}
+
+
+def check_traversal_scenes(renderer, asset_root):
+    check_scene(renderer, scenes.room(asset_root, w=64, h=36, spp=3, bounces=20))
+    check_scene(renderer, scenes.blob(asset_root, w=48, h=48, spp=2))
+    check_scene(renderer, scenes.stacked_duplicates(n=150, w=24, h=24))  # long leaf, several chunks, exact ties
+    check_scene(renderer, scenes.deep_chain(n=60, w=48, h=16))
+    check_scene(renderer, scenes.grid_wall(n=16, w=33, h=33))
+
+
+@pytest.mark.parametrize("share,pair_min,slots", [(0, 384, 8), (1, 1, 8), (1, 48, 2), (1, 300, 16)])
+def test_traversal_variants_give_identical_results(renderer, asset_root, share, pair_min, slots):
+    # one shape per lane and step, or pending triangle tests dealt out to all lanes;
+    # few LDS stack slots push most of the stack to the overflow area
+    renderer.set_option(F.RT_OPT_TRACE_SHARE, share)
     renderer.set_option(F.RT_OPT_TRACE_PAIR_MIN, pair_min)
+    renderer.set_option(F.RT_OPT_TRACE_LDS_SLOTS, slots)
     try:
-        check_scene(renderer, scenes.room(asset_root, w=64, h=36, spp=3, bounces=20))
-        check_scene(renderer, scenes.blob(asset_root, w=48, h=48, spp=2))
-        check_scene(renderer, scenes.stacked_duplicates(n=150, w=24, h=24))  # long leaf, several chunks, exact ties
-        check_scene(renderer, scenes.deep_chain(n=60, w=48, h=16))
-        check_scene(renderer, scenes.grid_wall(n=16, w=33, h=33))
+        check_traversal_scenes(renderer, asset_root)
     finally:
-        renderer.set_option(F.RT_OPT_TRACE_SHARE, 0)
-        renderer.set_option(F.RT_OPT_TRACE_PAIR_MIN, 48)
+        for k, v in TRACE_DEFAULTS.items():
+            renderer.set_option(k, v)
 
 
 def test_shared_reciprocal_division_is_ieee_division(renderer):
