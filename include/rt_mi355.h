@@ -219,7 +219,10 @@ typedef enum RtOption {
     RT_OPT_TRACE_PHASE_MIN = 5, /* lanes that must wait for a step to run it      */
     RT_OPT_TRACE_CHUNK = 6,     /* rays a wave reserves per queue atomic          */
     RT_OPT_TRACE_SHARE = 7,     /* 0/1: deal a wave's pending triangle tests out to all its lanes */
-    RT_OPT_TRACE_PAIR_MIN = 8   /* pending tests that trigger such a shared step  */
+    RT_OPT_TRACE_PAIR_MIN = 8,  /* pending tests that trigger such a shared step  */
+    RT_OPT_TRACE_WAVES = 9,     /* waves per traversal workgroup: 1, 8 or 16      */
+    RT_OPT_TRACE_CACHE_NODES = 10, /* top-of-tree branch records a multi-wave workgroup keeps in LDS (0..2048) */
+    RT_OPT_TRACE_REFILL_MIN = 11 /* idle lanes of a wave that trigger a refill from the queue (1..64) */
 } RtOption;
 
 typedef struct RtContext RtContext;

@@ -261,23 +261,49 @@ struct TraceArgs {
     uint32_t phase_min;      // a step runs for this many waiting lanes, or for the majority
     uint32_t chunk_max;      // most rays a wave reserves from the queue per atomic
     uint32_t pair_min;       // SHARE: pending (ray, triangle) pairs that trigger a shared shape step
+    uint32_t cache_nodes;    // branch records [0, cache_nodes) are copied to LDS by each workgroup
+    uint32_t refill_min;     // idle lanes that trigger a refill from the queue (1..64)
     int bounds_fast;         // every box coordinate is 0 or has magnitude in [2^-60, 2^59)
     unsigned long long* counters;  // [0] branch visits, [1] shape tests (COUNT only)
     unsigned long long* wave_tallies;  // six diagnostic words, triangle family only (COUNT only)
 };
 
-template <int KIND, bool COUNT, bool SHARE>
-__global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint2 s_stack[];  // [lds_slots][64]; SHARE: + 64 result keys + 64 marks
+// A workgroup is WAVES independent waves that share one thing: a copy in LDS of
+// the first `cache_nodes` branch records (the array is numbered breadth-first,
+// so these are the top levels of the tree, where most branch visits land).
+// The copy is laid out [16-byte quarter][record], so that lanes reading the
+// same quarter of different records spread over the LDS banks.  Dynamic LDS:
+// cache_nodes*64 bytes, then per wave lds_slots*512 (stack) + 512 (result keys)
+// + 256 (marks).
+__host__ __device__ inline size_t trace_lds_per_wave(uint32_t lds_slots) {
+    return static_cast<size_t>(lds_slots) * kTraceBlock * sizeof(uint2) + kTraceBlock * (sizeof(unsigned long long) + sizeof(uint32_t));
+}
+
+// Eight waves per SIMD leave each wave 96 scalar registers, of which the
+// system's trap handler keeps 16: the kernel is held to the 80 that remain.
+template <int KIND, bool COUNT, bool SHARE, int WAVES>
+__global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num_sgpr(80))) k_trace(TraceArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    float4* const s_nodes = reinterpret_cast<float4*>(s_raw);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned char* const s_wave = s_raw + static_cast<size_t>(a.cache_nodes) * sizeof(DNode) + wave * trace_lds_per_wave(a.lds_slots);
+    uint2* const s_stack = reinterpret_cast<uint2*>(s_wave);  // [lds_slots][64]; then 64 result keys, 64 marks (SHARE)
     unsigned long long* const s_res = reinterpret_cast<unsigned long long*>(s_stack + a.lds_slots * kTraceBlock);
     uint32_t* const s_mark = reinterpret_cast<uint32_t*>(s_res + kTraceBlock);
-    const uint32_t lane = threadIdx.x;
-    const uint32_t gtid = blockIdx.x * kTraceBlock + lane;
+    const uint32_t gtid = blockIdx.x * (kTraceBlock * WAVES) + threadIdx.x;
     const uint32_t n = *a.n_rays;
     const DNode* __restrict__ nodes = a.fam.nodes;
+    const uint32_t cache_nodes = WAVES > 1 ? a.cache_nodes : 0u;
+    if (WAVES > 1) {
+        const float4* src = reinterpret_cast<const float4*>(nodes);
+        for (uint32_t k = threadIdx.x; k < cache_nodes * 4u; k += kTraceBlock * WAVES)
+            s_nodes[(k & 3u) * cache_nodes + (k >> 2)] = src[k];
+        __syncthreads();
+    }
     // Reservation size: large for long queues (few atomics), one wave's worth for
     // short ones so that the rays still spread over all waves of the grid.
-    const uint32_t chunk = min(a.chunk_max, max(64u, (n / (2u * gridDim.x)) & ~63u));
+    const uint32_t chunk = min(a.chunk_max, max(64u, (n / (2u * gridDim.x * WAVES)) & ~63u));
     const int lds_slots = static_cast<int>(a.lds_slots);
 
     auto stack_store = [&](int slot, float dist, uint32_t ref) {
@@ -286,11 +312,19 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
         else a.spill[static_cast<size_t>(slot - lds_slots) * a.spill_stride + gtid] = e;
     };
     auto stack_load = [&](int slot) -> uint2 {
-        if (slot < lds_slots) return s_stack[slot * kTraceBlock + lane];
-        return a.spill[static_cast<size_t>(slot - lds_slots) * a.spill_stride + gtid];
+        uint2 e;
+        if (slot < lds_slots) {
+            e = s_stack[slot * kTraceBlock + lane];
+            // keeps the two loads apart: merged into one load through a selected address
+            // they become a flat load, which reaches LDS the slow way round
+            asm volatile("" : "+v"(e.x), "+v"(e.y));
+        } else {
+            e = a.spill[static_cast<size_t>(slot - lds_slots) * a.spill_stride + gtid];
+        }
+        return e;
     };
 
-    bool active = false, exhausted = false, fast = false;
+    bool active = false, exhausted = false, fast = false, fresh = false;
     uint32_t pool_next = 0, pool_end = 0;  // wave-uniform: rays reserved for this wave
     uint32_t ray = 0, best_i = kHitNone;
     int sp = 0;
@@ -304,10 +338,33 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
     uint32_t w_iters = 0, w_branch_runs = 0, w_branch_lanes = 0, w_shape_runs = 0, w_shape_lanes = 0, w_active_lanes = 0;
 
     for (;;) {
+        // ---- pop: a lane with nothing in hand takes the first stack entry that
+        //      survives the cull test of bvh.rs:252, or finishes its ray
+        if (active && item == kItemNone && shape_cur == shape_end) {
+            while (sp > 0) {
+                const uint2 e = stack_load(--sp);
+                if (!(best_t <= __uint_as_float(e.x))) {
+                    item = e.y;
+                    break;
+                }
+            }
+            if (item == kItemNone) {
+                // bvh.rs:300 + lib.rs:333: keep the earlier family on equal distance.
+                if (best_t < prior_t) {
+                    a.q.hit_t[ray] = best_t;
+                    a.q.hit_id[ray] = (static_cast<uint32_t>(KIND) << kHitKindShift) | best_i;
+                }
+                active = false;
+            }
+        }
+
+        // ---- refill: idle lanes (including those that have just finished) take new rays
         if (!exhausted || pool_next != pool_end) {
             const unsigned long long idle = __ballot(!active);
-            if (idle) {
-                const uint32_t n_idle = __popcll(idle);
+            const uint32_t n_idle = __popcll(idle);
+            // New rays come from HBM and the wave waits for them with its next loads, so
+            // idle lanes are refilled in batches rather than one by one.
+            if (n_idle >= a.refill_min || n_idle == 64u) {
                 if (pool_next == pool_end) {
                     // reserve the next block of the queue for this wave
                     uint32_t base = 0;
@@ -330,14 +387,9 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
                     sp = 0;
                     item = a.fam.root_ref;  // bvh.rs:246: the root is entered with its box untested
                     active = true;
-                    // regime in which div_by2 equals `/` (see refine_rcp)
-                    const int d_ok = int(magnitude_in(d.x, 0x1p-30f, 2.0f)) & int(magnitude_in(d.y, 0x1p-30f, 2.0f)) &
-                                     int(magnitude_in(d.z, 0x1p-30f, 2.0f));
-                    const int o_ok = (int(o.x == 0.0f) | int(magnitude_in(o.x, 0x1p-60f, 0x1p59f))) &
-                                     (int(o.y == 0.0f) | int(magnitude_in(o.y, 0x1p-60f, 0x1p59f))) &
-                                     (int(o.z == 0.0f) | int(magnitude_in(o.z, 0x1p-60f, 0x1p59f)));
-                    fast = (int(a.bounds_fast != 0) & d_ok & o_ok) != 0;
-                    rcp = f3(refine_rcp(d.x), refine_rcp(d.y), refine_rcp(d.z));
+                    // Nothing here looks at the ray yet, so the wave does not wait for these
+                    // loads now: they complete under the node loads of its first branch step.
+                    fresh = true;
                 }
                 pool_next += take;
             }
@@ -351,26 +403,6 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
             ++w_iters;
             w_active_lanes += __popcll(__ballot(active));
         }
-        // ---- pop: a lane with nothing in hand takes the first stack entry that
-        //      survives the cull test of bvh.rs:252, or finishes its ray
-        if (active && item == kItemNone && shape_cur == shape_end) {
-            while (sp > 0) {
-                const uint2 e = stack_load(--sp);
-                if (!(best_t <= __uint_as_float(e.x))) {
-                    item = e.y;
-                    break;
-                }
-            }
-            if (item == kItemNone) {
-                // bvh.rs:300 + lib.rs:333: keep the earlier family on equal distance.
-                if (best_t < prior_t) {
-                    a.q.hit_t[ray] = best_t;
-                    a.q.hit_id[ray] = (static_cast<uint32_t>(KIND) << kHitKindShift) | best_i;
-                }
-                active = false;
-            }
-        }
-
         // ---- branch step, bvh.rs:259-286
         const bool want_branch = item < kLeafBit;  // kItemNone and leaves have the top bit set
         {
@@ -381,9 +413,44 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
                 w_branch_lanes += n_b;
             }
             if (n_b > 0 && (n_b >= a.phase_min || n_b >= n_s) && want_branch) {
-                const float4* np = reinterpret_cast<const float4*>(nodes + item);
-                const float4 qx = np[0], qy = np[1], qz = np[2];  // (c0min, c1min, c0max, c1max) per axis
-                const uint4 q3 = reinterpret_cast<const uint4*>(np)[3];
+                float4 qx, qy, qz;  // (c0min, c1min, c0max, c1max) per axis
+                uint32_t ref0, ref1;
+                if (WAVES > 1 && item < cache_nodes) {
+                    qx = s_nodes[item];
+                    qy = s_nodes[cache_nodes + item];
+                    qz = s_nodes[2u * cache_nodes + item];
+                    const float4 r = s_nodes[3u * cache_nodes + item];
+                    ref0 = __float_as_uint(r.x);
+                    ref1 = __float_as_uint(r.y);
+                    // (keeps these LDS loads from being merged with the global ones below
+                    // into flat loads through a selected address)
+                    asm volatile("" : "+v"(qx.x), "+v"(qx.y), "+v"(qx.z), "+v"(qx.w), "+v"(qy.x), "+v"(qy.y), "+v"(qy.z), "+v"(qy.w));
+                    asm volatile("" : "+v"(qz.x), "+v"(qz.y), "+v"(qz.z), "+v"(qz.w), "+v"(ref0), "+v"(ref1));
+                } else {
+                    const float4* np = reinterpret_cast<const float4*>(nodes + item);
+                    qx = np[0];
+                    qy = np[1];
+                    qz = np[2];
+                    uint4 q3 = reinterpret_cast<const uint4*>(np)[3];
+                    // All sixteen loaded words are kept alive up to here, the two padding words
+                    // included: otherwise the register allocator may lay the last load over the
+                    // dead half of its neighbour, and the loads then run one after the other.
+                    asm volatile("" : "+v"(qx.x), "+v"(qx.y), "+v"(qx.z), "+v"(qx.w), "+v"(qy.x), "+v"(qy.y), "+v"(qy.z), "+v"(qy.w));
+                    asm volatile("" : "+v"(qz.x), "+v"(qz.y), "+v"(qz.z), "+v"(qz.w), "+v"(q3.x), "+v"(q3.y), "+v"(q3.z), "+v"(q3.w));
+                    ref0 = q3.x;
+                    ref1 = q3.y;
+                }
+                if (fresh) {
+                    // regime in which div_by2 equals `/` (see refine_rcp)
+                    const int d_ok = int(magnitude_in(d.x, 0x1p-30f, 2.0f)) & int(magnitude_in(d.y, 0x1p-30f, 2.0f)) &
+                                     int(magnitude_in(d.z, 0x1p-30f, 2.0f));
+                    const int o_ok = (int(o.x == 0.0f) | int(magnitude_in(o.x, 0x1p-60f, 0x1p59f))) &
+                                     (int(o.y == 0.0f) | int(magnitude_in(o.y, 0x1p-60f, 0x1p59f))) &
+                                     (int(o.z == 0.0f) | int(magnitude_in(o.z, 0x1p-60f, 0x1p59f)));
+                    fast = (int(a.bounds_fast != 0) & d_ok & o_ok) != 0;
+                    rcp = f3(refine_rcp(d.x), refine_rcp(d.y), refine_rcp(d.z));
+                    fresh = false;
+                }
                 float d0, d1;
                 bool h0, h1;
                 if (fast) {
@@ -410,10 +477,10 @@ __global__ void __launch_bounds__(kTraceBlock) k_trace(TraceArgs a) {
                 // the nearer kept in hand; on equal distances child 1 is the nearer.
                 const bool zero_near = d0 < d1;
                 if (h0 && h1) {
-                    stack_store(sp++, zero_near ? d1 : d0, zero_near ? q3.y : q3.x);
-                    item = zero_near ? q3.x : q3.y;
+                    stack_store(sp++, zero_near ? d1 : d0, zero_near ? ref1 : ref0);
+                    item = zero_near ? ref0 : ref1;
                 } else {
-                    item = h0 ? q3.x : (h1 ? q3.y : kItemNone);
+                    item = h0 ? ref0 : (h1 ? ref1 : kItemNone);
                 }
             }
         }

@@ -72,7 +72,10 @@ struct RtContext {
 
     std::map<std::pair<const void*, size_t>, int> trace_occupancy;  // (kernel, LDS bytes) -> workgroups per CU
     uint32_t max_grid_threads = 0; // upper bound of the traversal grid's threads (sizes the spill area)
-    uint32_t tune_lds_slots = 8, tune_phase_min = 24, tune_chunk_max = 256, tune_pair_min = 384;
+    uint32_t tune_lds_slots = 6, tune_phase_min = 24, tune_chunk_max = 256, tune_pair_min = 384;
+    uint32_t tune_refill_min = 12;  // idle lanes that trigger a refill
+    uint32_t tune_waves = 8;        // waves per traversal workgroup (1, 8 or 16)
+    uint32_t tune_cache_nodes = 144;  // branch records each multi-wave workgroup copies to LDS
     bool tune_share = true;  // deal pending (ray, triangle) pairs out to all lanes
     bool opt_count = false, opt_time = false;
     uint64_t opt_samples_in_flight = 0;  // 0 = automatic
@@ -382,35 +385,46 @@ unsigned long long* inline_counters(RtContext* ctx) { return ctx->opt_count ? ct
 // Launch one traversal kernel variant over a grid that is exactly what the
 // device keeps resident for its register and LDS use (the kernel is persistent:
 // its waves loop until the queue is drained).
-template <int KIND, bool COUNT, bool SHARE>
+template <int KIND, bool COUNT, bool SHARE, int WAVES>
 int launch_trace_variant(RtContext* ctx, TraceArgs a) {
-    const void* fn = reinterpret_cast<const void*>(&k_trace<KIND, COUNT, SHARE>);
-    // per wave: lds_slots stack entries per lane, then 64 result keys and 64 marks (SHARE)
-    const size_t lds = static_cast<size_t>(a.lds_slots) * kTraceBlock * sizeof(uint2) +
-                       kTraceBlock * (sizeof(unsigned long long) + sizeof(uint32_t));
+    const void* fn = reinterpret_cast<const void*>(&k_trace<KIND, COUNT, SHARE, WAVES>);
+    const int block = kTraceBlock * WAVES;
+    a.cache_nodes = WAVES > 1 ? std::min(ctx->tune_cache_nodes, ctx->fam[KIND].n_branches) : 0u;
+    const size_t lds = static_cast<size_t>(a.cache_nodes) * sizeof(DNode) + WAVES * trace_lds_per_wave(a.lds_slots);
     const auto key = std::make_pair(fn, lds);
     auto it = ctx->trace_occupancy.find(key);
     if (it == ctx->trace_occupancy.end()) {
+        if (lds > 64 * 1024)
+            HIP_TRY(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
         int per_cu = 0;
-        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kTraceBlock, lds));
-        if (per_cu < 1) return fail(ctx, RT_ERR_INVALID, "traversal workgroup does not fit a compute unit");
-        it = ctx->trace_occupancy.emplace(key, std::min(per_cu, 32)).first;
+        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, block, lds));
+        if (per_cu < 1) return fail(ctx, RT_ERR_INVALID, "traversal workgroup does not fit a compute unit (waves, LDS slots, cached nodes)");
+        per_cu = std::min(per_cu, 32 / WAVES);
+        if (std::getenv("RT_MI355_DEBUG_TALLIES"))
+            std::fprintf(stderr, "[rt_mi355] traversal kind %d: %d waves per workgroup, %zu bytes of LDS, %d workgroups per CU\n",
+                         KIND, WAVES, lds, per_cu);
+        it = ctx->trace_occupancy.emplace(key, per_cu).first;
     }
     const uint32_t grid = static_cast<uint32_t>(ctx->n_cus) * static_cast<uint32_t>(it->second);
-    a.spill_stride = grid * static_cast<uint32_t>(kTraceBlock);
+    a.spill_stride = grid * static_cast<uint32_t>(block);
     if (a.spill_stride > ctx->max_grid_threads) return fail(ctx, RT_ERR_INVALID, "traversal grid larger than the stack overflow area");
-    hipLaunchKernelGGL((k_trace<KIND, COUNT, SHARE>), dim3(grid), dim3(kTraceBlock), lds, ctx->stream, a);
+    hipLaunchKernelGGL((k_trace<KIND, COUNT, SHARE, WAVES>), dim3(grid), dim3(block), lds, ctx->stream, a);
     return RT_OK;
 }
 
 template <int KIND>
 int launch_trace_kind(RtContext* ctx, const TraceArgs& a) {
     if constexpr (KIND == 2) {
-        // the triangle family can deal its pending tests out to all lanes
-        if (ctx->tune_share)
-            return ctx->opt_count ? launch_trace_variant<2, true, true>(ctx, a) : launch_trace_variant<2, false, true>(ctx, a);
+        // the triangle family: shared shape step, optionally several waves per workgroup
+        if (ctx->tune_share) {
+            switch (ctx->tune_waves) {
+                case 8: return ctx->opt_count ? launch_trace_variant<2, true, true, 8>(ctx, a) : launch_trace_variant<2, false, true, 8>(ctx, a);
+                case 16: return ctx->opt_count ? launch_trace_variant<2, true, true, 16>(ctx, a) : launch_trace_variant<2, false, true, 16>(ctx, a);
+                default: return ctx->opt_count ? launch_trace_variant<2, true, true, 1>(ctx, a) : launch_trace_variant<2, false, true, 1>(ctx, a);
+            }
+        }
     }
-    return ctx->opt_count ? launch_trace_variant<KIND, true, false>(ctx, a) : launch_trace_variant<KIND, false, false>(ctx, a);
+    return ctx->opt_count ? launch_trace_variant<KIND, true, false, 1>(ctx, a) : launch_trace_variant<KIND, false, false, 1>(ctx, a);
 }
 
 // Nearest hit of every ray in `q` over the three families, in the reference's
@@ -430,6 +444,7 @@ int launch_trace(RtContext* ctx, const DQueue& q, const uint32_t* n_rays, uint32
         a.phase_min = ctx->tune_phase_min;
         a.chunk_max = ctx->tune_chunk_max;
         a.pair_min = ctx->tune_pair_min;
+        a.refill_min = ctx->tune_refill_min;
         a.bounds_fast = ctx->fam[kind].bounds_fast ? 1 : 0;
         a.counters = ctx->d_stats + 1 + 2 * kind;  // [branch visits, shape tests] of this family
         a.wave_tallies = kind == RT_SHAPE_TRIANGLE ? ctx->d_stats + 9 : nullptr;
@@ -658,6 +673,18 @@ int rt_set_option(RtContext* ctx, uint32_t option, uint64_t value) {
             ctx->tune_phase_min = static_cast<uint32_t>(value);
             return RT_OK;
         case RT_OPT_TRACE_SHARE: ctx->tune_share = value != 0; return RT_OK;
+        case RT_OPT_TRACE_REFILL_MIN:
+            if (value < 1 || value > 64) return fail(ctx, RT_ERR_INVALID, "refill threshold must be in 1..64");
+            ctx->tune_refill_min = static_cast<uint32_t>(value);
+            return RT_OK;
+        case RT_OPT_TRACE_WAVES:
+            if (value != 1 && value != 8 && value != 16) return fail(ctx, RT_ERR_INVALID, "waves per workgroup must be 1, 8 or 16");
+            ctx->tune_waves = static_cast<uint32_t>(value);
+            return RT_OK;
+        case RT_OPT_TRACE_CACHE_NODES:
+            if (value > 2048) return fail(ctx, RT_ERR_INVALID, "at most 2048 branch records can be kept in LDS");
+            ctx->tune_cache_nodes = static_cast<uint32_t>(value);
+            return RT_OK;
         case RT_OPT_TRACE_PAIR_MIN:
             if (value < 1 || value > 4096) return fail(ctx, RT_ERR_INVALID, "pair threshold must be in 1..4096");
             ctx->tune_pair_min = static_cast<uint32_t>(value);

@@ -11,6 +11,7 @@ import pytest
 
 from oracle import binding as O
 from raytracer_amd import _ffi as F
+from raytracer_amd.renderer import RtError
 
 from . import scenes
 
@@ -202,7 +203,8 @@ def test_resolve_matches_oracle(renderer):
                           O.resolve(s.params, sums, 4, True, 7, old.copy()))
 
 
-TRACE_DEFAULTS = {F.RT_OPT_TRACE_SHARE: 1, F.RT_OPT_TRACE_PAIR_MIN: 384, F.RT_OPT_TRACE_LDS_SLOTS: 8}
+TRACE_DEFAULTS = {F.RT_OPT_TRACE_SHARE: 1, F.RT_OPT_TRACE_PAIR_MIN: 384, F.RT_OPT_TRACE_LDS_SLOTS: 6,
+                  F.RT_OPT_TRACE_WAVES: 8, F.RT_OPT_TRACE_CACHE_NODES: 144, F.RT_OPT_TRACE_REFILL_MIN: 12}
 
 
 def check_traversal_scenes(renderer, asset_root):
@@ -225,6 +227,37 @@ def test_traversal_variants_give_identical_results(renderer, asset_root, share, 
     finally:
         for k, v in TRACE_DEFAULTS.items():
             renderer.set_option(k, v)
+
+
+@pytest.mark.parametrize("waves,cache_nodes,slots,refill", [(1, 0, 8, 1), (8, 0, 8, 64), (8, 3, 4, 12), (16, 1024, 8, 1),
+                                                           (16, 2048, 2, 33)])
+def test_workgroup_shapes_and_cached_tree_top(renderer, asset_root, waves, cache_nodes, slots, refill):
+    # one or several waves per workgroup sharing an LDS copy of the first branch
+    # records (more of them than the tree has, and very few, are both covered);
+    # refilling idle lanes one by one or only once the whole wave is idle
+    renderer.set_option(F.RT_OPT_TRACE_WAVES, waves)
+    renderer.set_option(F.RT_OPT_TRACE_CACHE_NODES, cache_nodes)
+    renderer.set_option(F.RT_OPT_TRACE_LDS_SLOTS, slots)
+    renderer.set_option(F.RT_OPT_TRACE_REFILL_MIN, refill)
+    try:
+        check_traversal_scenes(renderer, asset_root)
+    finally:
+        for k, v in TRACE_DEFAULTS.items():
+            renderer.set_option(k, v)
+
+
+def test_workgroup_that_cannot_fit_is_refused(renderer):
+    s = scenes.grid_wall(n=16, w=33, h=33)
+    renderer.upload(s)
+    renderer.set_option(F.RT_OPT_TRACE_WAVES, 16)
+    renderer.set_option(F.RT_OPT_TRACE_LDS_SLOTS, 64)  # 16 waves x 33 KB of stack exceed a compute unit's LDS
+    try:
+        with pytest.raises(RtError):
+            renderer.trace_primary(s.params, 0, False)
+    finally:
+        for k, v in TRACE_DEFAULTS.items():
+            renderer.set_option(k, v)
+    check_scene(renderer, s)  # the context stays usable
 
 
 def test_shared_reciprocal_division_is_ieee_division(renderer):
