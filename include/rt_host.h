@@ -56,6 +56,15 @@ RthImage* rth_image_open(const char* path, uint32_t width, uint32_t height, char
                          size_t err_len);
 uint8_t* rth_image_pixels(RthImage* image); /* width*height*3 bytes after the header */
 size_t rth_image_header_len(const RthImage* image);
+/* Copy the rows of tile (x, y, w, h) of the mapped image into / out of a packed
+ * w*h*3 buffer: what a renderer working tile by tile reads for the running
+ * average of /root/reference/src/lib.rs:286-292 and writes back afterwards (the
+ * reference works on per-chunk slices of the mapping, :201-204,248-295).
+ * Return 0, or -1 when the tile is not inside the image. */
+int rth_image_read_tile(const RthImage* image, uint32_t x, uint32_t y, uint32_t w, uint32_t h,
+                        uint8_t* tile);
+int rth_image_write_tile(RthImage* image, uint32_t x, uint32_t y, uint32_t w, uint32_t h,
+                         const uint8_t* tile);
 void rth_image_flush(RthImage* image);
 void rth_image_close(RthImage* image);
 

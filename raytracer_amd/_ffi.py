@@ -127,6 +127,8 @@ _HOST_SYMBOLS = {
     "rth_image_open": (C.c_void_p, [C.c_char_p, u32, u32, C.c_char_p, C.c_size_t]),
     "rth_image_pixels": (C.c_void_p, [C.c_void_p]),
     "rth_image_header_len": (C.c_size_t, [C.c_void_p]),
+    "rth_image_read_tile": (C.c_int, [C.c_void_p, u32, u32, u32, u32, C.c_void_p]),
+    "rth_image_write_tile": (C.c_int, [C.c_void_p, u32, u32, u32, u32, C.c_void_p]),
     "rth_image_flush": (None, [C.c_void_p]),
     "rth_image_close": (None, [C.c_void_p]),
 }

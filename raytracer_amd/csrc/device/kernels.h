@@ -307,9 +307,11 @@ __global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num
     const int lds_slots = static_cast<int>(a.lds_slots);
 
     auto stack_store = [&](int slot, float dist, uint32_t ref) {
-        const uint2 e = make_uint2(__float_as_uint(dist), ref);
-        if (slot < lds_slots) s_stack[slot * kTraceBlock + lane] = e;
-        else a.spill[static_cast<size_t>(slot - lds_slots) * a.spill_stride + gtid] = e;
+        // One 64-bit value, so that neither store can be split in two and the halves
+        // merged across the branches into a flat store through a selected address.
+        const unsigned long long e = (static_cast<unsigned long long>(ref) << 32) | __float_as_uint(dist);
+        if (slot < lds_slots) reinterpret_cast<unsigned long long*>(s_stack)[slot * kTraceBlock + lane] = e;
+        else reinterpret_cast<unsigned long long*>(a.spill)[static_cast<size_t>(slot - lds_slots) * a.spill_stride + gtid] = e;
     };
     auto stack_load = [&](int slot) -> uint2 {
         uint2 e;

@@ -23,6 +23,7 @@ struct RthImage {
     uint8_t* base = nullptr;
     size_t len = 0;
     size_t header_len = 0;
+    uint32_t width = 0, height = 0;
 };
 
 static void set_err(char* err, size_t err_len, const std::string& msg) {
@@ -62,6 +63,8 @@ RthImage* rth_image_open(const char* path, uint32_t width, uint32_t height, char
     img->base = static_cast<uint8_t*>(p);
     img->len = len;
     img->header_len = static_cast<size_t>(header_len);
+    img->width = width;
+    img->height = height;
     std::memcpy(img->base, header, img->header_len);
     return img;
 }
@@ -69,6 +72,34 @@ RthImage* rth_image_open(const char* path, uint32_t width, uint32_t height, char
 uint8_t* rth_image_pixels(RthImage* image) { return image ? image->base + image->header_len : nullptr; }
 
 size_t rth_image_header_len(const RthImage* image) { return image ? image->header_len : 0; }
+
+// Rows of a tile <-> a packed tile buffer.  A renderer that works on one tile
+// at a time (images larger than a GPU pass, or tiles dealt out to several GPUs)
+// reads the stored bytes of its tile for the running average of
+// /root/reference/src/lib.rs:286-292 and writes the new bytes back; the
+// reference does the same through its per-chunk slices of the mapping
+// (/root/reference/src/lib.rs:201-204,248-295).
+static bool tile_inside(const RthImage* image, uint32_t x, uint32_t y, uint32_t w, uint32_t h) {
+    return image && w && h && static_cast<uint64_t>(x) + w <= image->width && static_cast<uint64_t>(y) + h <= image->height;
+}
+
+int rth_image_read_tile(const RthImage* image, uint32_t x, uint32_t y, uint32_t w, uint32_t h, uint8_t* tile) {
+    if (!tile || !tile_inside(image, x, y, w, h)) return -1;
+    const uint8_t* px = image->base + image->header_len;
+    const size_t row = static_cast<size_t>(w) * 3;
+    for (uint32_t r = 0; r < h; ++r)
+        std::memcpy(tile + r * row, px + (static_cast<size_t>(y + r) * image->width + x) * 3, row);
+    return 0;
+}
+
+int rth_image_write_tile(RthImage* image, uint32_t x, uint32_t y, uint32_t w, uint32_t h, const uint8_t* tile) {
+    if (!tile || !tile_inside(image, x, y, w, h)) return -1;
+    uint8_t* px = image->base + image->header_len;
+    const size_t row = static_cast<size_t>(w) * 3;
+    for (uint32_t r = 0; r < h; ++r)
+        std::memcpy(px + (static_cast<size_t>(y + r) * image->width + x) * 3, tile + r * row, row);
+    return 0;
+}
 
 void rth_image_flush(RthImage* image) {
     if (image) ::msync(image->base, image->len, MS_ASYNC);

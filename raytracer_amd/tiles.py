@@ -1,0 +1,217 @@
+"""Tile-by-tile rendering into the memory-mapped image, on one GPU or many.
+
+The reference renders "infinitely large images" (README.md:18) because the
+framebuffer is only ever the mmap'd file: its workers lock one pixel chunk at a
+time and write it in place (/root/reference/src/lib.rs:201-204,248-295).  Here
+the unit is a rectangular tile.  A pass (the `incremental` samples, or all of
+them) is rendered tile by tile; each tile's bytes are read from the mapping
+when the running average of lib.rs:286-292 needs them, and written back when
+the tile is done, so the file is a complete image after every pass and
+`continue(n)` works on it exactly as on an untiled render.
+
+Several GPUs: ranks form groups of `group_size`; tiles are dealt to groups
+round-robin.  Inside a group every rank renders its share of the pass's samples
+of the tile and the group's radiance sums are reduced (RCCL) onto the group's
+first rank, which resolves and writes the tile.  With group_size 1 there is no
+collective at all: every rank maps the same file and writes its own tiles.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Callable, Protocol
+
+import numpy as np
+
+from . import _ffi as F
+from .distributed import sample_share
+
+
+class Image:
+    """The memory-mapped P6 file of /root/reference/src/lib.rs:64-89 +
+    src/mmap.rs:41-77 (created if missing, never truncated)."""
+
+    def __init__(self, path: str, width: int, height: int):
+        self._lib = F.host_lib()
+        err = C.create_string_buffer(512)
+        d = os.path.dirname(os.path.abspath(path))
+        os.makedirs(d, exist_ok=True)
+        self.width, self.height = int(width), int(height)
+        self._h = self._lib.rth_image_open(path.encode(), self.width, self.height, err, len(err))
+        if not self._h:
+            raise OSError(err.value.decode())
+
+    def pixels(self) -> np.ndarray:
+        """(height, width, 3) uint8 view of the mapping (valid until close)."""
+        n = self.width * self.height * 3
+        buf = (C.c_uint8 * n).from_address(self._lib.rth_image_pixels(self._h))
+        return np.frombuffer(buf, dtype=np.uint8).reshape(self.height, self.width, 3)
+
+    def read_tile(self, x: int, y: int, w: int, h: int) -> np.ndarray:
+        out = np.empty((h, w, 3), dtype=np.uint8)
+        if self._lib.rth_image_read_tile(self._h, x, y, w, h, out.ctypes.data) != 0:
+            raise ValueError("tile outside the image")
+        return out
+
+    def write_tile(self, x: int, y: int, tile: np.ndarray) -> None:
+        h, w, _ = tile.shape
+        tile = np.ascontiguousarray(tile, dtype=np.uint8)
+        if self._lib.rth_image_write_tile(self._h, x, y, w, h, tile.ctypes.data) != 0:
+            raise ValueError("tile outside the image")
+
+    def flush(self) -> None:
+        self._lib.rth_image_flush(self._h)
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.rth_image_close(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def tile_grid(width: int, height: int, tile_w: int, tile_h: int) -> list[tuple[int, int, int, int]]:
+    """(x, y, w, h) of every tile, row-major; edge tiles are smaller."""
+    if tile_w < 1 or tile_h < 1:
+        raise ValueError("tile size must be positive")
+    return [(x, y, min(tile_w, width - x), min(tile_h, height - y))
+            for y in range(0, height, tile_h) for x in range(0, width, tile_w)]
+
+
+def tiles_of_group(n_tiles: int, n_groups: int, group: int) -> range:
+    """Indices of the tiles group `group` of `n_groups` renders (round-robin, so
+    neighbouring tiles, which cost about the same, go to different groups)."""
+    if n_groups < 1 or not 0 <= group < n_groups:
+        raise ValueError("bad group")
+    return range(group, n_tiles, n_groups)
+
+
+def passes(params) -> tuple[int, int, bool, int]:
+    """(samples per pass, number of passes, running average?, first pass number),
+    /root/reference/src/lib.rs:206-211,233-234,286."""
+    chunk = int(params.incremental) or int(params.samples_per_pixel)
+    if chunk == 0 or params.samples_per_pixel % chunk:
+        raise ValueError("incremental must be non-zero and divide the samples per pixel")
+    running = bool(params.incremental) or bool(params.has_continue)
+    return chunk, int(params.samples_per_pixel) // chunk, running, int(params.continue_sampling) if params.has_continue else 0
+
+
+class TileBackend(Protocol):
+    """What the driver needs from a renderer.  `sums` objects are whatever the
+    group's reduce works on (torch tensors); only the backend looks inside."""
+
+    def render_tile_pass(self, params, old: np.ndarray | None) -> np.ndarray:
+        """All of one pass of one tile on this rank alone: `params` describes the
+        tile and the pass (see pass_params); returns the tile's new bytes."""
+
+    def render_sums(self, params, sample_begin: int, sample_count: int): ...
+
+    def zeros(self, params): ...
+
+    def resolve(self, params, sums, n_samples: int, running: bool, k: int, old: np.ndarray | None) -> np.ndarray: ...
+
+
+def pass_params(params, rect, chunk: int, running: bool, k: int):
+    """Render parameters for pass number `k` of tile `rect` as a render of its
+    own: `chunk` samples that resume at pass k (sample indices k*chunk ...,
+    running-average weight k), which is what lib.rs:233-234,286-292 do for the
+    pixels of one chunk."""
+    tp = params.copy()
+    tp.tile_x, tp.tile_y, tp.tile_w, tp.tile_h = rect
+    tp.samples_per_pixel = chunk
+    tp.incremental = 0
+    tp.has_continue = 1 if running else 0
+    tp.continue_sampling = k if running else 0
+    return tp
+
+
+def render_tiled(backend: TileBackend, image: Image, params, tile_w: int, tile_h: int, world: int = 1, rank: int = 0,
+                 group_size: int = 1, reduce_in_group: Callable | None = None, end_of_pass: Callable | None = None,
+                 progress: Callable | None = None) -> None:
+    """Render `params` (full image) into `image`.
+
+    reduce_in_group(sums): sum over the ranks of this rank's group onto the
+    group's first rank (dist.reduce on the group's process group); required when
+    group_size > 1.  end_of_pass(): called by every rank after each pass (a
+    barrier, so that the file is a whole image before anyone starts the next
+    pass).  progress(samples_done) is called on rank 0 like the reference's
+    "Samples: n" line.
+    """
+    if world % group_size:
+        raise ValueError("group size must divide the number of ranks")
+    if group_size > 1 and reduce_in_group is None:
+        raise ValueError("groups of several ranks need a reduce")
+    n_groups, group, member = world // group_size, rank // group_size, rank % group_size
+    chunk, n_passes, running, first_pass = passes(params)
+    grid = tile_grid(int(params.width), int(params.height), tile_w, tile_h)
+    mine = tiles_of_group(len(grid), n_groups, group)
+    for p in range(n_passes):
+        k = p + first_pass
+        for ti in mine:
+            rect = grid[ti]
+            x, y, w, h = rect
+            tp = pass_params(params, rect, chunk, running, k)
+            if group_size == 1:
+                old = image.read_tile(x, y, w, h) if running else None
+                image.write_tile(x, y, backend.render_tile_pass(tp, old))
+                continue
+            if running:
+                if k * chunk + chunk > 0xFFFFFFFF:
+                    raise ValueError("sample index overflow")
+                begin = k * chunk
+            else:
+                begin = 0
+            first, n = sample_share(begin, chunk, group_size, member)
+            sums = backend.render_sums(tp, first, n) if n > 0 else backend.zeros(tp)
+            reduce_in_group(sums)
+            if member == 0:
+                old = image.read_tile(x, y, w, h) if running else None
+                image.write_tile(x, y, backend.resolve(tp, sums, chunk, running, k, old))
+        if end_of_pass is not None:
+            end_of_pass()
+        if progress is not None and rank == 0:
+            progress(first_pass + (p + 1) * chunk)
+    image.flush()
+
+
+class GpuTileBackend:
+    """TileBackend over librt_mi355.so.  Radiance sums stay on the GPU: the
+    library writes them into a torch CUDA tensor (what RCCL reduces) through its
+    raw device pointer."""
+
+    def __init__(self, renderer, device=None):
+        self.renderer = renderer
+        self.device = device
+        self._buffer = None
+
+    def render_tile_pass(self, params, old):
+        h, w = params.tile_shape()
+        rgb8 = np.zeros((h, w, 3), dtype=np.uint8) if old is None else np.ascontiguousarray(old)
+        return self.renderer.render(params, rgb8)
+
+    def _tensor(self, params):
+        import torch
+
+        h, w = params.tile_shape()
+        n = h * w * 3
+        if self._buffer is None or self._buffer.numel() < n:
+            self._buffer = torch.empty(n, dtype=torch.float32, device=self.device)
+        return self._buffer[:n]
+
+    def render_sums(self, params, sample_begin, sample_count):
+        t = self._tensor(params)
+        self.renderer.render_sums_device(params, sample_begin, sample_count, t.data_ptr())
+        return t
+
+    def zeros(self, params):
+        return self._tensor(params).zero_()
+
+    def resolve(self, params, sums, n_samples, running, k, old):
+        h, w = params.tile_shape()
+        rgb8 = np.zeros((h, w, 3), dtype=np.uint8) if old is None else np.ascontiguousarray(old)
+        return self.renderer.resolve(params, sums.data_ptr(), n_samples, running_average=running, sample_iteration=k,
+                                     rgb8=rgb8, sums_on_device=True)

@@ -20,6 +20,7 @@ def asset_root(tmp_path_factory):
     root = str(tmp_path_factory.mktemp("assets"))
     assets.write_room(root, "room", detail=1)
     assets.write_blob(root, "blob", subdivisions=3)
+    assets.write_tree(root, "tree", n_leaves=6000)
     return root
 
 

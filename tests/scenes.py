@@ -51,6 +51,10 @@ def blob(asset_root, w=48, h=48, spp=4, bounces=10):
     return parse(assets.blob_scene_text("blob", w, h, spp, bounces), asset_root)
 
 
+def tree(asset_root, w=48, h=48, spp=3, bounces=12):
+    return parse(assets.tree_scene_text("tree", w, h, spp, bounces), asset_root)
+
+
 def _triangles(tris, material=0):
     out = np.zeros(len(tris), dtype=TRIANGLE_DT)
     t = np.asarray(tris, dtype=np.float32).reshape(-1, 3, 3)

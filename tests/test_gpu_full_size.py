@@ -4,6 +4,8 @@ the CPU oracle to render the whole frame: the GPU's full-frame result must
 contain, bit for bit, what the oracle computes for tiles of that frame; primary
 hits of the whole frame must equal the oracle's; and the result must not depend
 on how the frame is cut into tiles or sample batches."""
+import os
+
 import numpy as np
 import pytest
 
@@ -75,3 +77,69 @@ def test_result_is_independent_of_batching(renderer, room):
         assert np.array_equal(bits(got), bits(ref))
     renderer.set_option(F.RT_OPT_SAMPLES_IN_FLIGHT, 0)
     renderer.set_option(F.RT_OPT_TRACE_LDS_SLOTS, 8)
+
+
+# ---------------------------------------------------------------- island-tree class
+
+@pytest.fixture(scope="module")
+def tree(tmp_path_factory):
+    root = str(tmp_path_factory.mktemp("tree_full"))
+    n = assets.write_tree(root, "tree", n_leaves=250_000)
+    assert n > 500_000
+    return parse(assets.tree_scene_text("tree", 1000, 1000, 2, 50), root)
+
+
+def test_deep_tree_full_frame_contains_oracle_tiles(renderer, tree):
+    """Half a million thin overlapping quads: long leaves, a deep tree, 50 bounces."""
+    renderer.upload(tree)
+    renderer.set_option(F.RT_OPT_SAMPLES_IN_FLIGHT, 0)
+    renderer.set_option(F.RT_OPT_TRACE_LDS_SLOTS, 6)
+    gpu_hits = renderer.trace_primary(tree.params, 0, True)
+    full = renderer.render_sums(tree.params, 0, 2)
+    assert np.isfinite(full).all()
+    for x0, y0 in ((450, 380), (300, 520), (640, 300)):
+        p = tree.params.copy()
+        p.tile_x, p.tile_y, p.tile_w, p.tile_h = x0, y0, 64, 48
+        want = O.render_sums(tree, p, 0, 2, threads=8)
+        assert np.array_equal(bits(full[y0:y0 + 48, x0:x0 + 64]), bits(want))
+        cpu_hits = O.trace_primary(tree, p, 0, True)
+        band = gpu_hits[y0:y0 + 48, x0:x0 + 64]
+        assert np.array_equal(band["prim"], cpu_hits["prim"]) and np.array_equal(bits(band["t"]), bits(cpu_hits["t"]))
+
+
+# ---------------------------------------------------------------- 16K x 16K image
+
+def test_16k_image_through_the_mapped_file_with_continue(renderer, room, tmp_path):
+    """The 16384 x 16384 frame (805 MB of pixels) rendered tile by tile into the
+    memory-mapped file, one pass, then one more pass resumed from the file with
+    `continue`; spot tiles are compared with the CPU oracle run the same way."""
+    from raytracer_amd.tiles import GpuTileBackend, Image, render_tiled
+
+    W16 = 16384
+    renderer.upload(room)
+    renderer.set_option(F.RT_OPT_SAMPLES_IN_FLIGHT, 0)
+    p1 = room.params.copy()
+    p1.width = p1.height = W16
+    p1.top_edge[:] = [1.92, 0.0, 0.0]
+    p1.left_edge[:] = [0.0, -1.92, 0.0]  # square window
+    p1.samples_per_pixel, p1.incremental, p1.max_bounces = 1, 1, 6
+    p2 = p1.copy()
+    p2.has_continue, p2.continue_sampling = 1, 1
+    path = str(tmp_path / "big.ppm")
+    renderer.reset_stats()
+    with Image(path, W16, W16) as img:
+        render_tiled(GpuTileBackend(renderer), img, p1, 4096, 4096)
+    assert os.path.getsize(path) == len(b"P6\n16384 16384 255\n") + W16 * W16 * 3
+    with Image(path, W16, W16) as img:
+        render_tiled(GpuTileBackend(renderer), img, p2, 4096, 4096)
+        px = img.pixels()
+        assert renderer.stats()["paths"] == 2 * W16 * W16
+        assert px[::997, ::991].max() > 0
+        for x0, y0 in ((4090, 4090), (9000, 12000), (16300, 100)):  # the first straddles four tiles
+            t1, t2 = p1.copy(), p2.copy()
+            for t in (t1, t2):
+                t.tile_x, t.tile_y, t.tile_w, t.tile_h = x0, y0, 48, 32
+            want, _ = O.render(room, t1, threads=8)
+            want, _ = O.render(room, t2, want, threads=8)
+            assert np.array_equal(px[y0:y0 + 32, x0:x0 + 48], want)
+    os.remove(path)

@@ -71,6 +71,14 @@ def test_textured_room(renderer, asset_root):
     check_scene(renderer, scenes.room(asset_root, w=64, h=36, spp=3, bounces=20))
 
 
+def test_tree_of_overlapping_leaf_quads(renderer, asset_root):
+    # island-tree class: fan-triangulated quads, long leaves, textured and solid materials
+    s = scenes.tree(asset_root, w=56, h=56, spp=3, bounces=16)
+    counts = s.triangle_nodes["b"][(s.triangle_nodes["b"] & F.RT_LEAF_BIT) != 0] & 0x7FFFFFFF
+    assert counts.max() >= 15  # leaves too long for an inline count
+    check_scene(renderer, s)
+
+
 def test_empty_scene_is_sky(renderer):
     s = scenes.empty()
     gpu = check_scene(renderer, s)

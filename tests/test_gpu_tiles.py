@@ -1,0 +1,98 @@
+"""Tile-by-tile rendering into the memory-mapped image on the GPU: the tiled
+driver must store exactly the bytes of an untiled `rt_render` (and of the CPU
+oracle), through incremental passes and a `continue` restart from the file."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import binding as O
+from raytracer_amd import _ffi as F
+from raytracer_amd import assets
+from raytracer_amd.tiles import GpuTileBackend, Image, render_tiled
+
+from . import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _with(scene, spp, incremental=None, cont=None):
+    p = scene.params.copy()
+    p.samples_per_pixel = spp
+    p.incremental = incremental or 0
+    p.has_continue = 0 if cont is None else 1
+    p.continue_sampling = cont or 0
+    return p
+
+
+def test_tiled_image_equals_untiled_and_oracle(renderer, asset_root, tmp_path):
+    scene = scenes.room(asset_root, w=96, h=60, spp=4, bounces=10)
+    renderer.upload(scene)
+    p = _with(scene, 4, incremental=2)
+    want = renderer.render(p)
+    cpu, _ = O.render(scene, p, threads=4)
+    assert np.array_equal(want, cpu)
+    seen = []
+    with Image(str(tmp_path / "out.ppm"), 96, 60) as img:
+        render_tiled(GpuTileBackend(renderer), img, p, 40, 25, progress=seen.append)
+        assert np.array_equal(img.pixels(), want)
+    assert seen == [2, 4]
+
+
+def test_tiled_continue_from_the_file(renderer, asset_root, tmp_path):
+    scene = scenes.room(asset_root, w=64, h=48, spp=2, bounces=8)
+    renderer.upload(scene)
+    path = str(tmp_path / "c.ppm")
+    first, second = _with(scene, 4, incremental=2), _with(scene, 2, incremental=2, cont=2)
+    with Image(path, 64, 48) as img:
+        render_tiled(GpuTileBackend(renderer), img, first, 64, 16)
+    with Image(path, 64, 48) as img:  # a new mapping of the same file: its bytes are the checkpoint
+        render_tiled(GpuTileBackend(renderer), img, second, 20, 48)
+        got = img.pixels().copy()
+    want, _ = O.render(scene, first, threads=4)
+    want, _ = O.render(scene, second, want, threads=4)
+    assert np.array_equal(got, want)
+    # and the untiled GPU path agrees
+    gpu = renderer.render(second, renderer.render(first))
+    assert np.array_equal(got, gpu)
+
+
+def test_group_of_one_rank_uses_the_sums_path_identically(renderer, asset_root, tmp_path):
+    # the path several ranks of a group take (render_sums -> reduce -> resolve), with a group of one
+    import torch
+
+    scene = scenes.materials(w=48, h=32, spp=4)
+    renderer.upload(scene)
+    p = _with(scene, 4, incremental=2)
+    be = GpuTileBackend(renderer, torch.device("cuda", 0))
+
+    reduced = []
+    with Image(str(tmp_path / "g.ppm"), 48, 32) as img:
+        from raytracer_amd import tiles
+        grid = tiles.tile_grid(48, 32, 16, 16)
+        chunk, n_passes, running, first = tiles.passes(p)
+        for k in range(n_passes):
+            for rect in grid:
+                tp = tiles.pass_params(p, rect, chunk, running, k)
+                sums = be.render_sums(tp, k * chunk, chunk)
+                reduced.append(float(sums.sum()))
+                x, y, w, h = rect
+                img.write_tile(x, y, be.resolve(tp, sums, chunk, running, k, img.read_tile(x, y, w, h)))
+        got = img.pixels().copy()
+    assert np.array_equal(got, renderer.render(p)) and all(np.isfinite(reduced))
+
+
+def test_command_line_renderer_tiles_large_frames(asset_root, tmp_path):
+    exe = os.path.join(F.LIB_DIR, "rt_render")
+    scene_file = tmp_path / "scene"
+    scene_file.write_text(assets.room_scene_text("room", 80, 50, 4, 8, incremental=2))
+    env = dict(os.environ)
+    out_a, out_b = str(tmp_path / "a.ppm"), str(tmp_path / "b.ppm")
+    subprocess.run([exe, str(scene_file), out_a, "0"], cwd=asset_root, check=True, env=env, timeout=120)
+    subprocess.run([exe, str(scene_file), out_b, "0", "32"], cwd=asset_root, check=True, env=env, timeout=120)
+    a, b = open(out_a, "rb").read(), open(out_b, "rb").read()
+    assert a.startswith(b"P6\n80 50 255\n") and a == b
+    scene = scenes.room(asset_root, w=80, h=50, spp=4, bounces=8, incremental=2)
+    cpu, _ = O.render(scene, scene.params, threads=4)
+    assert a[len(b"P6\n80 50 255\n"):] == cpu.tobytes()

@@ -1,0 +1,159 @@
+"""The tile-by-tile image driver on CPU: tile geometry, the mmap'd image's tile
+copies, and the driver itself with the CPU oracle standing in for the GPU
+library behind the TileBackend interface — alone, and as two gloo processes
+(tile partition without a collective; sample partition with a reduce)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from raytracer_amd.tiles import Image, passes, render_tiled, tile_grid, tiles_of_group
+
+
+def test_tile_grid_covers_the_image_once():
+    for w, h, tw, th in ((64, 36, 16, 16), (50, 30, 16, 7), (5, 3, 8, 8), (16384, 16384, 2048, 2048)):
+        grid = tile_grid(w, h, tw, th)
+        cover = np.zeros((h, w), dtype=np.int32) if w * h < 1 << 20 else None
+        area = 0
+        for x, y, a, b in grid:
+            assert 0 < a <= tw and 0 < b <= th and x + a <= w and y + b <= h
+            area += a * b
+            if cover is not None:
+                cover[y:y + b, x:x + a] += 1
+        assert area == w * h
+        if cover is not None:
+            assert (cover == 1).all()
+    assert len(tile_grid(16384, 16384, 2048, 2048)) == 64
+    with pytest.raises(ValueError):
+        tile_grid(4, 4, 0, 1)
+
+
+def test_groups_partition_the_tiles():
+    for n_tiles, n_groups in ((64, 8), (7, 3), (2, 4), (1, 1)):
+        seen = sorted(t for g in range(n_groups) for t in tiles_of_group(n_tiles, n_groups, g))
+        assert seen == list(range(n_tiles))
+    with pytest.raises(ValueError):
+        tiles_of_group(4, 2, 2)
+
+
+def test_image_tiles_round_trip(tmp_path):
+    path = str(tmp_path / "t" / "img.ppm")
+    with Image(path, 7, 5) as img:
+        px = img.pixels()
+        px[...] = np.arange(7 * 5 * 3, dtype=np.uint8).reshape(5, 7, 3)
+        t = img.read_tile(2, 1, 4, 3)
+        assert np.array_equal(t, px[1:4, 2:6])
+        img.write_tile(3, 2, np.full((2, 3, 3), 255, np.uint8))
+        assert (px[2:4, 3:6] == 255).all() and px[1, 3, 0] == np.arange(105, dtype=np.uint8).reshape(5, 7, 3)[1, 3, 0]
+        with pytest.raises(ValueError):
+            img.read_tile(5, 0, 3, 1)
+        with pytest.raises(ValueError):
+            img.write_tile(0, 4, np.zeros((2, 1, 3), np.uint8))
+        img.flush()
+    raw = open(path, "rb").read()
+    assert raw.startswith(b"P6\n7 5 255\n") and len(raw) == len(b"P6\n7 5 255\n") + 105
+
+
+class OracleTileBackend:
+    """TileBackend over the CPU oracle (test stand-in for GpuTileBackend)."""
+
+    def __init__(self, scene):
+        self.scene = scene
+
+    def render_tile_pass(self, params, old):
+        from oracle import binding as O
+        rgb8, _ = O.render(self.scene, params, None if old is None else np.ascontiguousarray(old))
+        return rgb8
+
+    def render_sums(self, params, begin, count):
+        from oracle import binding as O
+        return torch.from_numpy(O.render_sums(self.scene, params, begin, count).reshape(-1).copy())
+
+    def zeros(self, params):
+        h, w = params.tile_shape()
+        return torch.zeros(h * w * 3, dtype=torch.float32)
+
+    def resolve(self, params, sums, n_samples, running, k, old):
+        from oracle import binding as O
+        h, w = params.tile_shape()
+        return O.resolve(params, sums.numpy().reshape(h, w, 3), n_samples, running, k,
+                         None if old is None else np.ascontiguousarray(old))
+
+
+def _scene(spp, incremental=None, cont=None):
+    from tests import scenes
+    s = scenes.materials(w=40, h=28, spp=spp)
+    p = s.params
+    p.incremental = incremental or 0
+    p.has_continue = 0 if cont is None else 1
+    p.continue_sampling = cont or 0
+    return s
+
+
+@pytest.mark.parametrize("incremental", [None, 2])
+def test_tiled_render_equals_untiled(tmp_path, incremental):
+    from oracle import binding as O
+    scene = _scene(4, incremental)
+    want, _ = O.render(scene, scene.params)
+    with Image(str(tmp_path / "a.ppm"), 40, 28) as img:
+        render_tiled(OracleTileBackend(scene), img, scene.params, 16, 12)
+        assert np.array_equal(img.pixels(), want)
+
+
+def test_tiled_continue_resumes_from_the_file(tmp_path):
+    from oracle import binding as O
+    path = str(tmp_path / "c.ppm")
+    first = _scene(4, incremental=2)
+    done = []
+    with Image(path, 40, 28) as img:
+        render_tiled(OracleTileBackend(first), img, first.params, 13, 28, progress=done.append)
+    assert done == [2, 4]
+    second = _scene(2, incremental=2, cont=2)  # one more pass, numbered 2
+    with Image(path, 40, 28) as img:               # reopened: the bytes are the checkpoint
+        render_tiled(OracleTileBackend(second), img, second.params, 40, 5, progress=done.append)
+        got = img.pixels().copy()
+    assert done == [2, 4, 4]  # lib.rs:238-246 prints continue + passes done * samples per pass
+    want, _ = O.render(first, first.params)
+    want, _ = O.render(second, second.params, want)
+    assert np.array_equal(got, want)
+    assert passes(second.params) == (2, 1, True, 2)
+
+
+def _worker(rank, world, port, group_size, path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scene = _scene(4, incremental=2)
+    n_groups = world // group_size
+    groups = [dist.new_group(list(range(g * group_size, (g + 1) * group_size))) for g in range(n_groups)]
+    mine = groups[rank // group_size]
+    root = (rank // group_size) * group_size
+    with Image(path, 40, 28) as img:
+        render_tiled(OracleTileBackend(scene), img, scene.params, 16, 16, world=world, rank=rank, group_size=group_size,
+                     reduce_in_group=(lambda t: dist.reduce(t, dst=root, op=dist.ReduceOp.SUM, group=mine)) if group_size > 1 else None,
+                     end_of_pass=dist.barrier)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world, group_size", [(2, 1), (2, 2), (3, 1)])
+def test_tiles_across_processes(tmp_path, world, group_size):
+    from oracle import binding as O
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    path = str(tmp_path / "m.ppm")
+    mp.spawn(_worker, args=(world, port, group_size, path), nprocs=world, join=True)
+    with Image(path, 40, 28) as img:
+        got = img.pixels().copy()
+    scene = _scene(4, incremental=2)
+    want, _ = O.render(scene, scene.params)
+    if group_size == 1:
+        assert np.array_equal(got, want)  # tile partition: no arithmetic differs
+    else:
+        # sample partition inside the group: partial sums are added in another
+        # association, which can move a truncated byte by one
+        assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
