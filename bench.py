@@ -44,7 +44,7 @@ def recorded_traffic(args):
     FETCH_SIZE doubled as measured for 128-B requests on gfx950, plus WRITE_SIZE).
     Counters cannot be collected inside a timed run, so the figure is the one
     recorded for this same workload, or None when the workload differs."""
-    if (args.width, args.height, args.spp, args.bounces, args.detail) != (1920, 1080, 256, 60, 4):
+    if (args.workload, args.width, args.height, args.spp, args.bounces, args.detail) != ("room", 1920, 1080, 256, 60, 4):
         return None
     try:
         with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
@@ -53,22 +53,57 @@ def recorded_traffic(args):
         return None
 
 
+WORKLOADS = {
+    # name: (width, height, spp, bounces) defaults and what the scene is
+    "room": (1920, 1080, 256, 60),   # the metric's configuration (breakfast-room class)
+    "blob": (1920, 1080, 64, 10),    # bunny class: smooth mesh with vertex normals, one grey material
+    "tree": (2000, 2000, 32, 50),    # island-tree class: a million thin overlapping quads, deep tree
+    # the room at 16384 x 16384 into the memory-mapped image file, tile by tile; a step is one
+    # more one-sample pass over the whole image, resumed from the file (`continue`)
+    "room16k": (16384, 16384, 1, 60),
+}
+
+
+def scene_text(args) -> tuple[str, str]:
+    """(scene-file text, one-line description) of the chosen workload."""
+    if args.workload == "room16k":
+        text = assets.room_scene_text("room", args.width, args.height, args.spp, args.bounces, incremental=args.spp)
+        text = text.replace("1.92 0 0, 0 -1.08 0", "1.92 0 0, 0 -1.92 0")  # square window for the square image
+        return (text, "breakfast-room-class generated room ({n} triangles) at {w}x{h} into the memory-mapped image, "
+                      "4096x4096 tiles, {spp} spp per pass, {b} bounces, every step resumes from the file")
+    if args.workload == "room":
+        return (assets.room_scene_text("room", args.width, args.height, args.spp, args.bounces),
+                "breakfast-room-class generated room ({n} triangles, 5 ppm textures, metal/glass/light spheres), "
+                "{w}x{h}, {spp} spp, {b} bounces, camera of scenes/breakfast-room")
+    if args.workload == "blob":
+        return (assets.blob_scene_text("blob", args.width, args.height, args.spp, args.bounces),
+                "bunny-class generated smooth mesh ({n} triangles, vertex normals, default grey Lambertian), "
+                "{w}x{h}, {spp} spp, {b} bounces, camera of scenes/bunny")
+    return (assets.tree_scene_text("tree", args.width, args.height, args.spp, args.bounces),
+            "island-tree-class generated tree ({n} triangles: overlapping leaf quads, textured island and bark), "
+            "{w}x{h}, {spp} spp, {b} bounces, camera of scenes/island-tree")
+
+
 def load_scene(args) -> Scene:
-    """Generate (once) and parse the room scene.  The parsed arrays are cached
+    """Generate (once) and parse the workload's scene.  The parsed arrays are cached
     next to the generated OBJ so that several ranks do not each rebuild the BVH."""
-    root = os.path.join(ROOT, "assets_cache", f"room_d{args.detail}")
+    root = os.path.join(ROOT, "assets_cache", f"{'room' if args.workload == 'room16k' else args.workload}_d{args.detail}")
     cache = os.path.join(root, "scene_v1.npz")
-    text = assets.room_scene_text("room", args.width, args.height, args.spp, args.bounces)
+    text, _ = scene_text(args)
     fields = ("spheres", "planes", "triangles", "vertex_normals", "tex_coords", "bary_precomputed", "materials",
               "texels", "sphere_nodes", "plane_nodes", "triangle_nodes")
     if os.path.exists(cache):
         z = np.load(cache, allow_pickle=False)
-        params = parse(assets.room_scene_text("room", args.width, args.height, args.spp, args.bounces)
-                       .replace("obj((room/room))\n", ""), root).params
+        # the screen/camera block comes from the text; the obj(...) line is dropped so nothing is re-read
+        params = parse("\n".join(l for l in text.splitlines() if not l.startswith("obj(")) + "\n", root).params
         return Scene(params, *[z[k] for k in fields])
     t0 = time.time()
-    if not os.path.exists(os.path.join(root, "obj", "room", "room.obj")):
+    if args.workload in ("room", "room16k") and not os.path.exists(os.path.join(root, "obj", "room", "room.obj")):
         assets.write_room(root, "room", detail=args.detail)
+    elif args.workload == "blob" and not os.path.exists(os.path.join(root, "obj", "blob.obj")):
+        assets.write_blob(root, "blob", subdivisions=min(8, 2 + args.detail))   # detail 4: 81,920 triangles
+    elif args.workload == "tree" and not os.path.exists(os.path.join(root, "obj", "tree.obj")):
+        assets.write_tree(root, "tree", n_leaves=125_000 * args.detail)          # detail 4: 1.04e6 triangles
     scene = parse(text, root)
     tmp = cache + f".{os.getpid()}.tmp.npz"
     np.savez(tmp, **{k: getattr(scene, k) for k in fields})
@@ -86,8 +121,9 @@ def cpu_baseline(scene: Scene, args) -> dict:
 
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
     p = scene.params.copy()
-    p.tile_w, p.tile_h = args.width // 2, args.height // 2
-    p.tile_x, p.tile_y = args.width // 4, args.height // 4
+    p.tile_w, p.tile_h = min(args.width // 2, 960), min(args.height // 2, 540)
+    p.tile_x, p.tile_y = (args.width - p.tile_w) // 2, (args.height - p.tile_h) // 2
+    p.has_continue = p.continue_sampling = p.incremental = 0
     t0 = time.perf_counter()
     O.render_sums(scene, p, 0, 1, threads=threads)
     probe = time.perf_counter() - t0
@@ -107,16 +143,21 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=256)
-    ap.add_argument("--bounces", type=int, default=60)
-    ap.add_argument("--detail", type=int, default=4, help="tessellation of the generated room (4 = 2.9e5 triangles)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="room",
+                    help="room = the metric's configuration; blob / tree = the bunny-class and island-tree-class scenes")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None)
+    ap.add_argument("--bounces", type=int, default=None)
+    ap.add_argument("--detail", type=int, default=4, help="size of the generated scene (4 = 2.9e5 / 8.2e4 / 1.0e6 triangles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development aid: run all ranks on GPU 0 and reduce over gloo through host memory, to exercise "
                          "the multi-rank control flow on a one-GPU machine (numbers are meaningless)")
     args = ap.parse_args()
+    dw, dh, dspp, db = WORKLOADS[args.workload]
+    args.width, args.height = args.width or dw, args.height or dh
+    args.spp, args.bounces = args.spp or dspp, args.bounces if args.bounces is not None else db
 
     import torch
     import torch.distributed as dist
@@ -155,8 +196,14 @@ def main() -> None:
     r = Renderer(local_rank)
     r.upload(scene)
     params = scene.params
-    backend = GpuSumsBackend(r, params, device)
-    rgb8 = np.zeros((args.height, args.width, 3), dtype=np.uint8)
+    tiled = args.workload == "room16k"
+    count_params = params
+    if tiled:  # traversal statistics from one tile-sized window in the middle of the frame
+        count_params = params.copy()
+        count_params.tile_x, count_params.tile_y = args.width // 2 - 960, args.height // 2 - 540
+        count_params.tile_w, count_params.tile_h = 1920, 1080
+    backend = GpuSumsBackend(r, count_params, device)
+    rgb8 = None if tiled else np.zeros((args.height, args.width, 3), dtype=np.uint8)
 
     def reduce_to_root(t):
         if args.rehearse_on_one_gpu:
@@ -167,10 +214,29 @@ def main() -> None:
             dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
         torch.cuda.synchronize()
 
-    def step():
-        sums = render_pass(backend, 0, args.spp, world, rank, reduce_to_root)
-        if rank == 0:
-            r.resolve(params, sums.data_ptr(), args.spp, rgb8=rgb8, sums_on_device=True)
+    step_no = [0]
+    if args.workload == "room16k":
+        # tiles dealt to the ranks, every rank writing its tiles into the one mapped file:
+        # no collective on the data path, one barrier per pass
+        import tempfile
+
+        from raytracer_amd.tiles import GpuTileBackend, Image, render_tiled
+
+        path = os.path.join(os.environ.get("TMPDIR", tempfile.gettempdir()), f"rt_bench_{args.width}x{args.height}.ppm")
+        image = Image(path, args.width, args.height)
+        tile_backend = GpuTileBackend(r, device)
+
+        def step():
+            p = params.copy()
+            p.has_continue, p.continue_sampling = 1, step_no[0]
+            step_no[0] += 1
+            render_tiled(tile_backend, image, p, 4096, 4096, world=world, rank=rank, group_size=1,
+                         end_of_pass=(dist.barrier if world > 1 else None))
+    else:
+        def step():
+            sums = render_pass(backend, 0, args.spp, world, rank, reduce_to_root)
+            if rank == 0:
+                r.resolve(params, sums.data_ptr(), args.spp, rgb8=rgb8, sums_on_device=True)
 
     # ---- traversal statistics of this workload (untimed, counting kernels)
     count_spp = min(args.spp, 2)
@@ -217,7 +283,7 @@ def main() -> None:
         rays_per_s = segments / dt
         traffic = recorded_traffic(args)
         out = {
-            "metric": "Mrays/s (all bounces) breakfast-room 1080p",
+            "metric": "Mrays/s (all bounces) breakfast-room 1080p" if args.workload == "room" else f"Mrays/s (all bounces) {args.workload}",
             "value": round(rays_per_s / 1e6, 3),
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -230,11 +296,11 @@ def main() -> None:
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"breakfast-room-class generated room ({len(scene.triangles)} triangles, 5 ppm textures, "
-                            f"metal/glass/light spheres), {args.width}x{args.height}, {args.spp} spp, "
-                            f"{args.bounces} bounces, camera of scenes/breakfast-room",
-                "partition": "samples" if world > 1 else "none",
-                "collective": "reduce(sum) of f32 radiance per step" if world > 1 else "none",
+                "workload": scene_text(args)[1].format(n=len(scene.triangles), w=args.width, h=args.height, spp=args.spp,
+                                                       b=args.bounces),
+                "partition": ("tiles" if tiled else "samples") if world > 1 else "none",
+                "collective": ("none (each rank writes its tiles into the mapped file)" if tiled
+                               else "reduce(sum) of f32 radiance per step") if world > 1 else "none",
             },
             "samples_per_s": round(paths / dt, 1),
             "rays_per_sample": round(rays_per_path, 3),
@@ -263,6 +329,10 @@ def main() -> None:
             out["cpu_baseline"] = cpu_baseline(scene, args)
         print(json.dumps(out), flush=True)
 
+    if tiled:
+        image.close()
+        if rank == 0:
+            os.remove(path)
     r.close()
     if world > 1:
         dist.destroy_process_group()
