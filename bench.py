@@ -70,7 +70,7 @@ def scene_text(args) -> tuple[str, str]:
         text = assets.room_scene_text("room", args.width, args.height, args.spp, args.bounces, incremental=args.spp)
         text = text.replace("1.92 0 0, 0 -1.08 0", "1.92 0 0, 0 -1.92 0")  # square window for the square image
         return (text, "breakfast-room-class generated room ({n} triangles) at {w}x{h} into the memory-mapped image, "
-                      "4096x4096 tiles, {spp} spp per pass, {b} bounces, every step resumes from the file")
+                      "{t}x{t} tiles, {spp} spp per pass, {b} bounces, every step resumes from the file")
     if args.workload == "room":
         return (assets.room_scene_text("room", args.width, args.height, args.spp, args.bounces),
                 "breakfast-room-class generated room ({n} triangles, 5 ppm textures, metal/glass/light spheres), "
@@ -150,6 +150,7 @@ def main() -> None:
     ap.add_argument("--spp", type=int, default=None)
     ap.add_argument("--bounces", type=int, default=None)
     ap.add_argument("--detail", type=int, default=4, help="size of the generated scene (4 = 2.9e5 / 8.2e4 / 1.0e6 triangles)")
+    ap.add_argument("--tile", type=int, default=4096, help="tile edge of the room16k workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development aid: run all ranks on GPU 0 and reduce over gloo through host memory, to exercise "
@@ -230,7 +231,7 @@ def main() -> None:
             p = params.copy()
             p.has_continue, p.continue_sampling = 1, step_no[0]
             step_no[0] += 1
-            render_tiled(tile_backend, image, p, 4096, 4096, world=world, rank=rank, group_size=1,
+            render_tiled(tile_backend, image, p, args.tile, args.tile, world=world, rank=rank, group_size=1,
                          end_of_pass=(dist.barrier if world > 1 else None))
     else:
         def step():
@@ -297,7 +298,7 @@ def main() -> None:
             "data": "synthetic",
             "config": {
                 "workload": scene_text(args)[1].format(n=len(scene.triangles), w=args.width, h=args.height, spp=args.spp,
-                                                       b=args.bounces),
+                                                       b=args.bounces, t=args.tile),
                 "partition": ("tiles" if tiled else "samples") if world > 1 else "none",
                 "collective": ("none (each rank writes its tiles into the mapped file)" if tiled
                                else "reduce(sum) of f32 radiance per step") if world > 1 else "none",
