@@ -84,7 +84,7 @@ def scene_text(args) -> tuple[str, str]:
             "{w}x{h}, {spp} spp, {b} bounces, camera of scenes/island-tree")
 
 
-def load_scene(args) -> Scene:
+def load_scene(args, renderer=None) -> Scene:
     """Generate (once) and parse the workload's scene.  The parsed arrays are cached
     next to the generated OBJ so that several ranks do not each rebuild the BVH."""
     root = os.path.join(ROOT, "assets_cache", f"{'room' if args.workload == 'room16k' else args.workload}_d{args.detail}")
@@ -104,7 +104,7 @@ def load_scene(args) -> Scene:
         assets.write_blob(root, "blob", subdivisions=min(8, 2 + args.detail))   # detail 4: 81,920 triangles
     elif args.workload == "tree" and not os.path.exists(os.path.join(root, "obj", "tree.obj")):
         assets.write_tree(root, "tree", n_leaves=125_000 * args.detail)          # detail 4: 1.04e6 triangles
-    scene = parse(text, root)
+    scene = parse(text, root, renderer=renderer)  # triangle BVH built on the GPU (same tree as the host builder's)
     tmp = cache + f".{os.getpid()}.tmp.npz"
     np.savez(tmp, **{k: getattr(scene, k) for k in fields})
     os.replace(tmp, cache)
@@ -185,16 +185,15 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # rank 0 builds the cache first so the others only load it
-    if rank == 0:
-        scene = load_scene(args)
-    barrier()
-    if rank != 0:
-        scene = load_scene(args)
-
     from raytracer_amd.renderer import Renderer
 
     r = Renderer(local_rank)
+    # rank 0 builds the cache first so the others only load it
+    if rank == 0:
+        scene = load_scene(args, r)
+    barrier()
+    if rank != 0:
+        scene = load_scene(args, r)
     r.upload(scene)
     params = scene.params
     tiled = args.workload == "room16k"

@@ -30,6 +30,17 @@ typedef struct RthScene RthScene;
 RthScene* rth_parse_scene(const char* text, const char* base_dir, char* err, size_t err_len);
 void rth_free_scene(RthScene* scene);
 
+/* The same, with the triangle family's `BvhNode::new`
+ * (/root/reference/src/config.rs:132-134) handed to `build_triangles`: a function
+ * with the contract of rth_build_bvh_triangles (permute `shapes` in place, return
+ * a malloc'd node array and its length) that may return NULL to decline, in
+ * which case the host builder is used.  This is how rt_build_bvh_triangles of
+ * rt_mi355.h (construction on the GPU) is plugged in without this library
+ * depending on HIP. */
+typedef RtNode* (*RthTriangleBvhFn)(void* user, RtTriangle* shapes, uint32_t n, uint32_t* n_nodes);
+RthScene* rth_parse_scene_with(const char* text, const char* base_dir, RthTriangleBvhFn build_triangles,
+                               void* user, char* err, size_t err_len);
+
 /* Views into the parsed scene; valid until rth_free_scene. */
 void rth_scene_desc(const RthScene* scene, RtSceneDesc* out);
 void rth_scene_params(const RthScene* scene, RtRenderParams* out);

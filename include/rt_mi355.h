@@ -282,6 +282,18 @@ int rt_trace_primary(RtContext* ctx, const RtRenderParams* params,
 int rt_trace_rays(RtContext* ctx, const float* origins, const float* directions,
                   uint64_t n_rays, RtHitRecord* out);
 
+/* `BvhNode::new` for the triangle family, /root/reference/src/bvh.rs:48-224, on
+ * the GPU: the same contract as the host builder (rth_build_bvh_triangles in
+ * rt_host.h) and the same result — `shapes` is permuted in place exactly as the
+ * reference permutes its slice (/root/reference/src/config.rs:113-134) and
+ * `*nodes` receives the node array in the reference's push order (malloc'd;
+ * release with rt_free).  Box coordinates equal the host builder's as numbers
+ * (a zero may carry the other sign).  Needs no scene.  Coordinates must be
+ * finite: otherwise RT_ERR_INVALID, and the family is built on the host. */
+int rt_build_bvh_triangles(RtContext* ctx, RtTriangle* shapes, uint32_t n, RtNode** nodes,
+                           uint32_t* n_nodes);
+void rt_free(void* p);
+
 /* Device self-tests (no counterpart in the reference).  RT_SELF_TEST_DIVISION
  * checks, on about `n_cases` operand pairs, that the traversal kernel's
  * shared-reciprocal division returns exactly the bits of an IEEE division over

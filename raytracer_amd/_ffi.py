@@ -109,13 +109,18 @@ _DEVICE_SYMBOLS = {
                              u32, C.c_void_p]),
     "rt_trace_primary": (C.c_int, [C.c_void_p, C.POINTER(RtRenderParams), u32, C.c_int, C.c_void_p]),
     "rt_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u64, C.c_void_p]),
+    "rt_build_bvh_triangles": (C.c_int, [C.c_void_p, C.c_void_p, u32, C.POINTER(C.c_void_p), C.POINTER(u32)]),
+    "rt_free": (None, [C.c_void_p]),
     "rt_self_test": (C.c_int, [C.c_void_p, u32, u64, C.POINTER(u64)]),
     "rt_get_stats": (C.c_int, [C.c_void_p, C.POINTER(RtStats)]),
     "rt_reset_stats": (C.c_int, [C.c_void_p]),
 }
 
+RthTriangleBvhFn = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_void_p, u32, C.POINTER(u32))
+
 _HOST_SYMBOLS = {
     "rth_parse_scene": (C.c_void_p, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
+    "rth_parse_scene_with": (C.c_void_p, [C.c_char_p, C.c_char_p, RthTriangleBvhFn, C.c_void_p, C.c_char_p, C.c_size_t]),
     "rth_free_scene": (None, [C.c_void_p]),
     "rth_scene_desc": (None, [C.c_void_p, C.POINTER(RtSceneDesc)]),
     "rth_scene_params": (None, [C.c_void_p, C.POINTER(RtRenderParams)]),

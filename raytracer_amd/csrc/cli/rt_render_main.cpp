@@ -32,6 +32,13 @@ static void progress(uint32_t samples_done, void*) {
     std::fflush(stdout);
 }
 
+// RthTriangleBvhFn over rt_build_bvh_triangles; NULL (decline) sends the parser to the host builder.
+static RtNode* build_triangles_on_gpu(void* user, RtTriangle* shapes, uint32_t n, uint32_t* n_nodes) {
+    RtNode* nodes = nullptr;
+    if (rt_build_bvh_triangles(static_cast<RtContext*>(user), shapes, n, &nodes, n_nodes) != RT_OK) return nullptr;
+    return nodes;
+}
+
 int main(int argc, char** argv) {
     const std::string scene_path = argc > 1 ? argv[1] : "scene";
     const std::string out_path = argc > 2 ? argv[2] : "target/out.ppm";
@@ -46,8 +53,16 @@ int main(int argc, char** argv) {
     std::stringstream text;
     text << in.rdbuf();
 
+    RtContext* ctx = nullptr;
+    int rc = rt_create(gpu, &ctx);
+    if (rc != RT_OK) {
+        std::fprintf(stderr, "no usable GPU (rt_create returned %d)\n", rc);
+        return 1;
+    }
+
+    // scene ingest on the host, with the triangle BVH built on the GPU (same tree)
     char err[1024] = {0};
-    RthScene* scene = rth_parse_scene(text.str().c_str(), ".", err, sizeof err);
+    RthScene* scene = rth_parse_scene_with(text.str().c_str(), ".", build_triangles_on_gpu, ctx, err, sizeof err);
     if (!scene) {
         std::fprintf(stderr, "scene error: %s\n", err);
         return 1;
@@ -65,12 +80,6 @@ int main(int argc, char** argv) {
         return 1;
     }
 
-    RtContext* ctx = nullptr;
-    int rc = rt_create(gpu, &ctx);
-    if (rc != RT_OK) {
-        std::fprintf(stderr, "no usable GPU (rt_create returned %d)\n", rc);
-        return 1;
-    }
     rc = rt_upload_scene(ctx, &desc);
     const uint64_t n_pixels = static_cast<uint64_t>(params.width) * params.height;
     if (tile_edge == 0 && n_pixels > (1ull << 24)) tile_edge = 4096;

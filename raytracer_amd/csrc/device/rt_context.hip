@@ -615,6 +615,16 @@ int download_hits(RtContext* ctx, const DQueue& q, size_t n, RtHitRecord* out) {
 
 }  // namespace
 
+// For the other translation units of this library (bvh_build.hip): record an
+// error on the context; make the context's GPU current and hand out its stream.
+int rt_context_fail(RtContext* ctx, int code, const std::string& msg) { return fail(ctx, code, msg); }
+int rt_context_device(RtContext* ctx, hipStream_t* stream) {
+    if (!ctx) return RT_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    *stream = ctx->stream;
+    return RT_OK;
+}
+
 extern "C" {
 
 uint32_t rt_abi_version(void) { return RT_ABI_VERSION; }

@@ -13,13 +13,18 @@ struct RthScene {
 extern "C" {
 
 RthScene* rth_parse_scene(const char* text, const char* base_dir, char* err, size_t err_len) {
+    return rth_parse_scene_with(text, base_dir, nullptr, nullptr, err, err_len);
+}
+
+RthScene* rth_parse_scene_with(const char* text, const char* base_dir, RthTriangleBvhFn build_triangles, void* user,
+                               char* err, size_t err_len) {
     RthScene* s = new (std::nothrow) RthScene;
     if (!s) {
         if (err && err_len) std::snprintf(err, err_len, "out of memory");
         return nullptr;
     }
     try {
-        rth::parse_scene(text ? text : "", base_dir ? base_dir : ".", s->scene);
+        rth::parse_scene(text ? text : "", base_dir ? base_dir : ".", s->scene, build_triangles, user);
         return s;
     } catch (const std::exception& e) {
         if (err && err_len) std::snprintf(err, err_len, "%s", e.what());

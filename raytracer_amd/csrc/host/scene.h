@@ -5,6 +5,7 @@
 #include <string>
 #include <vector>
 
+#include "rt_host.h"
 #include "rt_mi355.h"
 
 namespace rth {
@@ -44,7 +45,9 @@ void load_obj(const std::string& path, Scene& scene, std::vector<RtTriangle>& ou
 std::vector<uint8_t> load_ppm_p6(const std::string& path, uint32_t& width, uint32_t& height);
 
 // /root/reference/src/config.rs:15-145.  Throws std::runtime_error.
-void parse_scene(const std::string& text, const std::string& base_dir, Scene& scene);
+// `triangle_builder` (may be null) replaces the host builder for the triangle family.
+void parse_scene(const std::string& text, const std::string& base_dir, Scene& scene,
+                 RthTriangleBvhFn triangle_builder = nullptr, void* builder_user = nullptr);
 
 std::vector<RtNode> build_bvh(RtSphere* s, uint32_t n);
 std::vector<RtNode> build_bvh(RtPlane* s, uint32_t n);

@@ -23,6 +23,8 @@
 #include <cstring>
 #include <stdexcept>
 
+#include <cstdlib>
+
 #include "scene.h"
 #include "text.h"
 #include "vec3.h"
@@ -125,7 +127,8 @@ std::vector<std::vector<std::string>> items_of(const std::string& value) {
 
 }  // namespace
 
-void parse_scene(const std::string& text, const std::string& base_dir, Scene& scene) {
+void parse_scene(const std::string& text, const std::string& base_dir, Scene& scene,
+                 RthTriangleBvhFn triangle_builder, void* builder_user) {
     const std::vector<std::string> ls = lines(text);
     size_t next = 0;
     bool have_screen = false, have_camera = false, have_spheres = false, have_planes = false,
@@ -215,8 +218,21 @@ void parse_scene(const std::string& text, const std::string& base_dir, Scene& sc
 
     scene.sphere_nodes = build_bvh(scene.spheres.data(), static_cast<uint32_t>(scene.spheres.size()));
     scene.plane_nodes = build_bvh(scene.planes.data(), static_cast<uint32_t>(scene.planes.size()));
-    scene.triangle_nodes =
-        build_bvh(scene.triangles.data(), static_cast<uint32_t>(scene.triangles.size()));
+    // The triangle family is where construction time goes; a caller may supply
+    // another builder with the same contract (the GPU one) and this falls back to
+    // the host builder when that one declines.
+    const uint32_t n_tris = static_cast<uint32_t>(scene.triangles.size());
+    bool built = false;
+    if (triangle_builder) {
+        uint32_t n_nodes = 0;
+        RtNode* nodes = triangle_builder(builder_user, scene.triangles.data(), n_tris, &n_nodes);
+        if (nodes) {
+            scene.triangle_nodes.assign(nodes, nodes + n_nodes);
+            std::free(nodes);
+            built = true;
+        }
+    }
+    if (!built) scene.triangle_nodes = build_bvh(scene.triangles.data(), n_tris);
 }
 
 }  // namespace rth

@@ -61,6 +61,22 @@ class Renderer:
         self._check(self._lib.rt_upload_scene(self._ctx, C.byref(d)))
         self._scene = scene
 
+    def build_bvh_triangles(self, triangles: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+        """`BvhNode::new` (/root/reference/src/bvh.rs:48) for triangles, on the GPU.
+        Returns (nodes, triangles in post-build order); the input is not modified."""
+        from .scene import NODE_DT, TRIANGLE_DT
+
+        tris = np.ascontiguousarray(triangles, dtype=TRIANGLE_DT).copy()
+        raw, n_nodes = C.c_void_p(), F.u32(0)
+        self._check(self._lib.rt_build_bvh_triangles(self._ctx, tris.ctypes.data if tris.size else None, tris.size,
+                                                     C.byref(raw), C.byref(n_nodes)))
+        try:
+            buf = (C.c_char * (n_nodes.value * NODE_DT.itemsize)).from_address(raw.value)
+            nodes = np.frombuffer(buf, dtype=NODE_DT, count=n_nodes.value).copy()
+        finally:
+            self._lib.rt_free(raw)
+        return nodes, tris
+
     # ------------------------------------------------------------------ render
     def render_into(self, params, pixels_ptr, progress=None) -> None:
         """rt_render into caller memory (an address or ctypes pointer)."""

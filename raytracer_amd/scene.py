@@ -165,13 +165,26 @@ class Scene:
             lib.rth_image_close(img)
 
 
-def parse(text: str, base_dir: str = ".") -> Scene:
+def parse(text: str, base_dir: str = ".", renderer=None) -> Scene:
     """`config::parse`, /root/reference/src/config.rs:15: scene text to Scene.
     `base_dir` is where `obj/<name>.obj` is looked up (the reference uses the
-    working directory).  Raises ValueError where the reference panics."""
+    working directory).  Raises ValueError where the reference panics.
+    With a `renderer` (raytracer_amd.Renderer) the triangle BVH is built on its
+    GPU (same tree; the host builder remains the fallback for non-finite data)."""
     lib = F.host_lib()
     err = C.create_string_buffer(1024)
-    handle = lib.rth_parse_scene(text.encode(), base_dir.encode(), err, len(err))
+    if renderer is None:
+        handle = lib.rth_parse_scene(text.encode(), base_dir.encode(), err, len(err))
+    else:
+        dev = F.device_lib()
+
+        def build(_user, shapes, n, n_nodes):
+            nodes = C.c_void_p()
+            rc = dev.rt_build_bvh_triangles(renderer._ctx, shapes, n, C.byref(nodes), n_nodes)
+            return nodes.value if rc == 0 else None
+
+        hook = F.RthTriangleBvhFn(build)
+        handle = lib.rth_parse_scene_with(text.encode(), base_dir.encode(), hook, None, err, len(err))
     if not handle:
         raise ValueError(err.value.decode())
     try:

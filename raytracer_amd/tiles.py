@@ -181,7 +181,10 @@ def render_tiled(backend: TileBackend, image: Image, params, tile_w: int, tile_h
 class GpuTileBackend:
     """TileBackend over librt_mi355.so.  Radiance sums stay on the GPU: the
     library writes them into a torch CUDA tensor (what RCCL reduces) through its
-    raw device pointer."""
+    raw device pointer.  A process that uses torch on the GPU as well (groups of
+    several ranks) must `import torch` before the first Renderer is created:
+    torch ships its own HIP runtime, and whichever runtime is loaded first serves
+    both; torch does not find the GPU through the system's."""
 
     def __init__(self, renderer, device=None):
         self.renderer = renderer

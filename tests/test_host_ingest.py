@@ -298,3 +298,37 @@ def test_image_sink_keeps_old_pixels(tmp_path):
     assert bytes((C.c_uint8 * 45).from_address(lib.rth_image_pixels(img))) == bytes(range(45))
     lib.rth_image_close(img)
     assert not lib.rth_image_open(str(tmp_path / "no" / "dir.ppm").encode(), 2, 2, err, len(err)) and err.value
+
+
+def test_parser_takes_a_triangle_builder_and_falls_back_when_it_declines(asset_root):
+    """rth_parse_scene_with: the hook the GPU builder is plugged in through."""
+    from raytracer_amd import assets
+    from raytracer_amd.scene import _view, NODE_DT, TRIANGLE_DT
+    lib = F.host_lib()
+    text = assets.blob_scene_text("blob", 16, 16, 1, 2).encode()
+    calls = []
+
+    def parse_with(fn):
+        err = C.create_string_buffer(256)
+        hook = F.RthTriangleBvhFn(fn)
+        h = lib.rth_parse_scene_with(text, asset_root.encode(), hook, None, err, len(err))
+        assert h, err.value
+        d = F.RtSceneDesc()
+        lib.rth_scene_desc(h, C.byref(d))
+        out = (_view(d.triangle_nodes, d.n_triangle_nodes, NODE_DT), _view(d.triangles, d.n_triangles, TRIANGLE_DT))
+        lib.rth_free_scene(h)
+        return out
+
+    def decline(_user, shapes, n, n_nodes):
+        calls.append(("decline", n))
+        return None
+
+    def through_host_builder(_user, shapes, n, n_nodes):
+        calls.append(("host", n))
+        return lib.rth_build_bvh_triangles(shapes, n, n_nodes)
+
+    plain = obj_scene(asset_root, "blob")
+    for fn in (decline, through_host_builder):
+        nodes, tris = parse_with(fn)
+        assert nodes.tobytes() == plain.triangle_nodes.tobytes() and tris.tobytes() == plain.triangles.tobytes()
+    assert calls == [("decline", len(plain.triangles)), ("host", len(plain.triangles))]
