@@ -56,6 +56,12 @@ unsafe extern "C" {
         ctx: *mut RtContext, params: *const RtRenderParams, rgb8: *mut u8,
         progress: Option<unsafe extern "C" fn(u32, *mut c_void)>, user: *mut c_void,
     ) -> c_int;
+    /// Optional: `BvhNode::new` (src/bvh.rs:48) for the triangle slice on the GPU.  Permutes
+    /// `shapes` in place like the host builder; `*nodes` is malloc'd, release it with `rt_free`.
+    pub fn rt_build_bvh_triangles(
+        ctx: *mut RtContext, shapes: *mut RtTriangle, n: u32, nodes: *mut *mut RtNode, n_nodes: *mut u32,
+    ) -> c_int;
+    pub fn rt_free(p: *mut c_void);
 }
 
 /// What `Scene::render` (src/lib.rs:188) becomes: flatten, upload, render into
