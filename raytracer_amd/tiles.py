@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+from concurrent.futures import ThreadPoolExecutor
 from typing import Callable, Protocol
 
 import numpy as np
@@ -149,16 +150,29 @@ def render_tiled(backend: TileBackend, image: Image, params, tile_w: int, tile_h
     chunk, n_passes, running, first_pass = passes(params)
     grid = tile_grid(int(params.width), int(params.height), tile_w, tile_h)
     mine = tiles_of_group(len(grid), n_groups, group)
+    # Tile copies between the mapping and packed buffers run on a helper thread, so
+    # that the GPU renders tile i while tile i-1 is written and tile i+1 is read
+    # (the copies are plain memcpy over up to hundreds of MB of page cache).
+    copier = ThreadPoolExecutor(max_workers=1)
     for p in range(n_passes):
         k = p + first_pass
-        for ti in mine:
+        if group_size == 1:
+            rects = [grid[ti] for ti in mine]
+            ahead = copier.submit(image.read_tile, *rects[0]) if running and rects else None
+            writing = None
+            for n, rect in enumerate(rects):
+                old = ahead.result() if ahead is not None else None
+                ahead = copier.submit(image.read_tile, *rects[n + 1]) if running and n + 1 < len(rects) else None
+                new = backend.render_tile_pass(pass_params(params, rect, chunk, running, k), old)
+                if writing is not None:
+                    writing.result()
+                writing = copier.submit(image.write_tile, rect[0], rect[1], new)
+            if writing is not None:
+                writing.result()
+        for ti in (mine if group_size > 1 else ()):
             rect = grid[ti]
             x, y, w, h = rect
             tp = pass_params(params, rect, chunk, running, k)
-            if group_size == 1:
-                old = image.read_tile(x, y, w, h) if running else None
-                image.write_tile(x, y, backend.render_tile_pass(tp, old))
-                continue
             if running:
                 if k * chunk + chunk > 0xFFFFFFFF:
                     raise ValueError("sample index overflow")
@@ -175,6 +189,7 @@ def render_tiled(backend: TileBackend, image: Image, params, tile_w: int, tile_h
             end_of_pass()
         if progress is not None and rank == 0:
             progress(first_pass + (p + 1) * chunk)
+    copier.shutdown()
     image.flush()
 
 
