@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_DIR = os.path.join(_HERE, "lib")
+# RT_MI355_LIB_DIR points at another build of the two libraries (A/B timing of kernel variants).
+LIB_DIR = os.environ.get("RT_MI355_LIB_DIR") or os.path.join(_HERE, "lib")
 
 RT_ABI_VERSION = 1
 RT_LEAF_BIT = 0x80000000

@@ -25,6 +25,7 @@ ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--bounces", type=int, default=60)
 ap.add_argument("--detail", type=int, default=4)
+ap.add_argument("--workload", default="room", choices=["room", "blob", "tree"])
 ap.add_argument("--combo", action="append", default=[], help="waves,cache,slots,refill: run exactly these instead of the product")
 ap.add_argument("knobs", nargs="*")
 args = ap.parse_args()
