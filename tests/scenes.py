@@ -55,6 +55,27 @@ def tree(asset_root, w=48, h=48, spp=3, bounces=12):
     return parse(assets.tree_scene_text("tree", w, h, spp, bounces), asset_root)
 
 
+def many_spheres(n=300, n_planes=20, w=64, h=48, spp=3, bounces=10, seed=4):
+    """Sphere and plane families too large to be scanned where rays are created:
+    the sphere family gets a real tree, the planes one long leaf (infinite boxes
+    are never split, /root/reference/src/shapes.rs:175-181)."""
+    rng = np.random.default_rng(seed)
+    kinds = ["lambertian", "metal 0", "metal 0.3", "glass 1.5", "light"]
+    spheres = ", ".join(
+        "({:.4f} {:.4f} {:.4f}, {:.4f}, {}, {:.3f} {:.3f} {:.3f})".format(
+            *rng.uniform(-3, 3, 2), rng.uniform(-4, 1), rng.uniform(0.05, 0.3), kinds[i % 5 if i % 11 else 4],
+            *rng.uniform(0.2, 1.0, 3)) for i in range(n))
+    dirs = rng.normal(size=(n_planes, 3))
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    planes = ", ".join(  # a closed cell of planes around the spheres and the camera
+        "({:.3f} {:.3f} {:.3f}, {:.3f} {:.3f} {:.3f}, {}, {:.3f} {:.3f} {:.3f})".format(
+            *(d * rng.uniform(9, 14)), *(-d), kinds[i % 3], *rng.uniform(0.2, 0.9, 3))
+        for i, d in enumerate(dirs))
+    text = (f"screen(-2 2 1, 4 0 0, 0 -3 0, {w}, {h}, {spp}, {bounces})\ncamera(0 0.5 6)\n"
+            f"spheres({spheres})\nplanes({planes})\ntriangles()\n")
+    return parse(text)
+
+
 def _triangles(tris, material=0):
     out = np.zeros(len(tris), dtype=TRIANGLE_DT)
     t = np.asarray(tris, dtype=np.float32).reshape(-1, 3, 3)

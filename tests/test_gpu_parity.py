@@ -79,6 +79,15 @@ def test_tree_of_overlapping_leaf_quads(renderer, asset_root):
     check_scene(renderer, s)
 
 
+def test_large_sphere_and_plane_families_are_traversed(renderer):
+    # more than 16 shapes per family: each goes through its own traversal launches
+    s = scenes.many_spheres()
+    assert len(s.sphere_nodes) > 20 and len(s.plane_nodes) == 1 and len(s.planes) == 20
+    check_scene(renderer, s)
+    hits = renderer.trace_primary(s.params, 0, True)
+    assert {int(k) for k in np.unique(hits["kind"])} >= {F.RT_SHAPE_SPHERE, F.RT_SHAPE_PLANE}
+
+
 def test_empty_scene_is_sky(renderer):
     s = scenes.empty()
     gpu = check_scene(renderer, s)
