@@ -151,6 +151,7 @@ def main() -> None:
     ap.add_argument("--bounces", type=int, default=None)
     ap.add_argument("--detail", type=int, default=4, help="size of the generated scene (4 = 2.9e5 / 8.2e4 / 1.0e6 triangles)")
     ap.add_argument("--tile", type=int, default=4096, help="tile edge of the room16k workload")
+    ap.add_argument("--chains", type=int, default=None, help="independent chains a batch is split into (library default: 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development aid: run all ranks on GPU 0 and reduce over gloo through host memory, to exercise "
@@ -195,6 +196,8 @@ def main() -> None:
     if rank != 0:
         scene = load_scene(args, r)
     r.upload(scene)
+    chains = 2 if args.chains is None else args.chains  # 2 is the library's default
+    r.set_option(F.RT_OPT_CHAINS, chains)
     params = scene.params
     tiled = args.workload == "room16k"
     count_params = params
@@ -317,6 +320,12 @@ def main() -> None:
                 "bytes_per_ray": round(trace_bytes_per_ray, 1),
                 "avg_launch_ms": round(my_trace_ms / my_launches, 4),
                 "launches": int(my_launches),
+                # A batch runs as `chains` independent chains whose traversal launches are resident side by
+                # side, each on its share of the wave slots: `achieved` is the rate of one launch (the
+                # definition: its bytes / its duration); all launches together move at least this much per
+                # second of wall time on the device:
+                "launch_concurrency": chains,
+                "achieved_all_launches_over_wall": round(trace_bytes_per_ray * my_segments / dt / 1e9, 2),
                 "kernel_time_share": round(my_trace_ms / 1e3 / dt, 4),
                 "per_ray": {"branch_visits": round(B, 3), "triangle_tests": round(T, 3), "sphere_tests": round(S, 3),
                             "plane_tests": round(P, 3), "hit_fraction": round(H, 4)},

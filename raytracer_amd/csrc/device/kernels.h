@@ -656,13 +656,18 @@ struct FrameArgs {
 // lib.rs:261-268.  Path i of the batch is sample (first_sample + i / n_pixels)
 // of tile pixel (i % n_pixels); its generator starts at the sub-stream of
 // (sample, image pixel) and the two jitter draws come first, x then y.
-__global__ void k_raygen(FrameArgs f, DScene sc, DQueue q, uint32_t n_paths, uint32_t n_pixels,
+//
+// The launch covers paths [first_path, first_path + n_paths) of the batch and
+// writes them to queue entries [0, n_paths): a batch may be split over several
+// queues; a path's result slot is its number in the whole batch.
+__global__ void k_raygen(FrameArgs f, DScene sc, DQueue q, uint32_t first_path, uint32_t n_paths, uint32_t n_pixels,
                          unsigned long long first_sample, int jitter, uint32_t* n_rays_out,
                          unsigned long long* test_counters) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) *n_rays_out = n_paths;
-    if (i >= n_paths) return;
-    const uint32_t j = i / n_pixels, pix = i - j * n_pixels;
+    const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
+    if (local == 0) *n_rays_out = n_paths;
+    if (local >= n_paths) return;
+    const uint32_t path = first_path + local;
+    const uint32_t j = path / n_pixels, pix = path - j * n_pixels;
     const uint32_t x = f.x0 + pix % f.tile_w, y = f.y0 + pix / f.tile_w;
     const unsigned long long sample = first_sample + j;
     const unsigned long long k =
@@ -679,16 +684,16 @@ __global__ void k_raygen(FrameArgs f, DScene sc, DQueue q, uint32_t n_paths, uin
     const F3 pixel = (f3(f.top_left) + a) + b;
     const F3 cam = f3(f.camera);
     const F3 dir = normalize(pixel - cam);
-    q.origin[i] = make_float4(cam.x, cam.y, cam.z, 0.0f);
-    q.direction[i] = make_float4(dir.x, dir.y, dir.z, 0.0f);
-    q.throughput[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-    q.rng[i] = make_uint2(static_cast<uint32_t>(s), static_cast<uint32_t>(s >> 32));
-    q.slot[i] = i;
+    q.origin[local] = make_float4(cam.x, cam.y, cam.z, 0.0f);
+    q.direction[local] = make_float4(dir.x, dir.y, dir.z, 0.0f);
+    q.throughput[local] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    q.rng[local] = make_uint2(static_cast<uint32_t>(s), static_cast<uint32_t>(s >> 32));
+    q.slot[local] = path;
     float ht;
     uint32_t hid;
     seed_hit(sc, cam, dir, ht, hid, test_counters);
-    q.hit_t[i] = ht;
-    q.hit_id[i] = hid;
+    q.hit_t[local] = ht;
+    q.hit_id[local] = hid;
 }
 
 // Caller-supplied rays (rt_trace_rays).

@@ -32,6 +32,8 @@ struct Family {
     bool bounds_fast = false;  // all box coordinates are 0 or of magnitude in [2^-60, 2^59)
 };
 
+constexpr int kMaxChains = 4;
+
 struct Workspace {
     size_t cap_paths = 0;   // records per queue
     size_t cap_pixels = 0;  // pixels of sums / rgb8
@@ -51,6 +53,11 @@ struct RtContext {
     int device = 0;
     int n_cus = 0;
     hipStream_t stream = nullptr;
+    hipStream_t chain_stream[4] = {nullptr, nullptr, nullptr, nullptr};  // [0] = stream; the others carry further chains of a batch
+    hipEvent_t chain_event[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t launch_stream = nullptr;  // where traversal launches go (stream, or a chain's stream)
+    uint32_t wave_cap_now = 0;            // traversal waves per CU while chains run side by side (0 = no cap)
+    uint32_t n_chains = 2;                // independent chains a large batch is split into (1 = none)
     std::string error;
 
     bool has_scene = false;
@@ -73,6 +80,7 @@ struct RtContext {
     std::map<std::pair<const void*, size_t>, int> trace_occupancy;  // (kernel, LDS bytes) -> workgroups per CU
     uint32_t max_grid_threads = 0; // upper bound of the traversal grid's threads (sizes the spill area)
     uint32_t tune_lds_slots = 6, tune_phase_min = 24, tune_chunk_max = 256, tune_pair_min = 384;
+    uint32_t tune_waves_per_cu = 0; // traversal waves resident per CU (0 = all the kernel's occupancy allows)
     uint32_t tune_refill_min = 12;  // idle lanes that trigger a refill
     uint32_t tune_waves = 8;        // waves per traversal workgroup (1, 8 or 16)
     uint32_t tune_cache_nodes = 144;  // branch records each multi-wave workgroup copies to LDS
@@ -307,11 +315,11 @@ int ensure_workspace(RtContext* ctx, size_t n_paths, size_t n_pixels, size_t n_b
         (void)hipFree(w.counters);
         w.counters = nullptr;
         w.cap_bounces = 0;
-        // queue lengths [0..B], then 3 cursors for each of B bounces
-        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&w.counters), (n_bounces + 1 + 3 * n_bounces + 4) * sizeof(uint32_t)));
+        // queue lengths [0..B], then 3 cursors for each of B bounces; one such block per chain
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&w.counters), kMaxChains * (n_bounces + 1 + 3 * n_bounces + 4) * sizeof(uint32_t)));
         w.cap_bounces = n_bounces;
     }
-    return ensure_pinned(ctx, n_bounces + 8);
+    return ensure_pinned(ctx, kMaxChains * (n_bounces + 1 + 3 * n_bounces + 4) + 8);
 }
 
 struct Region {
@@ -405,10 +413,13 @@ int launch_trace_variant(RtContext* ctx, TraceArgs a) {
                          KIND, WAVES, lds, per_cu);
         it = ctx->trace_occupancy.emplace(key, per_cu).first;
     }
-    const uint32_t grid = static_cast<uint32_t>(ctx->n_cus) * static_cast<uint32_t>(it->second);
+    // share of the CU's 32 wave slots: the caller's setting, or the overlapped render loop's
+    uint32_t wave_cap = ctx->wave_cap_now ? ctx->wave_cap_now : (ctx->tune_waves_per_cu ? ctx->tune_waves_per_cu : 32u);
+    const uint32_t per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(static_cast<uint32_t>(it->second), wave_cap / WAVES));
+    const uint32_t grid = static_cast<uint32_t>(ctx->n_cus) * per_cu;
     a.spill_stride = grid * static_cast<uint32_t>(block);
     if (a.spill_stride > ctx->max_grid_threads) return fail(ctx, RT_ERR_INVALID, "traversal grid larger than the stack overflow area");
-    hipLaunchKernelGGL((k_trace<KIND, COUNT, SHARE, WAVES>), dim3(grid), dim3(block), lds, ctx->stream, a);
+    hipLaunchKernelGGL((k_trace<KIND, COUNT, SHARE, WAVES>), dim3(grid), dim3(block), lds, ctx->launch_stream, a);
     return RT_OK;
 }
 
@@ -457,13 +468,13 @@ int launch_trace(RtContext* ctx, const DQueue& q, const uint32_t* n_rays, uint32
                     ctx->events.push_back(ev);
                 }
             }
-            HIP_TRY(ctx, hipEventRecord(ctx->events[ctx->events_used], ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->events[ctx->events_used], ctx->launch_stream));
         }
         const int rc = kind == 0 ? launch_trace_kind<0>(ctx, a) : kind == 1 ? launch_trace_kind<1>(ctx, a) : launch_trace_kind<2>(ctx, a);
         if (rc) return rc;
         HIP_TRY(ctx, hipGetLastError());
         if (timed) {
-            HIP_TRY(ctx, hipEventRecord(ctx->events[ctx->events_used + 1], ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->events[ctx->events_used + 1], ctx->launch_stream));
             ctx->events_used += 2;
             ctx->stats.trace_launches++;
         }
@@ -508,6 +519,9 @@ size_t choose_samples_in_flight(const RtContext* ctx, size_t n_pixels, uint32_t 
     return std::max<size_t>(s, 1);
 }
 
+int render_batch_overlapped(RtContext* ctx, const FrameArgs& f, const DScene& sc, uint32_t B, uint32_t n_paths,
+                            uint32_t n_pix, unsigned long long first_sample, uint64_t* segments_out);
+
 // The bounce loop over samples [s_begin, s_begin + count) of the region into
 // the workspace's running sums (lib.rs:260-279 for every pixel).
 int render_sums_device(RtContext* ctx, const RtRenderParams* p, const Region& r, uint32_t s_begin, uint32_t count) {
@@ -528,17 +542,26 @@ int render_sums_device(RtContext* ctx, const RtRenderParams* p, const Region& r,
     for (uint32_t b0 = 0; b0 < count; b0 += static_cast<uint32_t>(S)) {
         const uint32_t nb = std::min<uint32_t>(static_cast<uint32_t>(S), count - b0);
         const uint32_t n_paths = nb * n_pix;
-        HIP_TRY(ctx, hipMemsetAsync(counts, 0, std::max<size_t>(counter_words, 1) * sizeof(uint32_t), ctx->stream));
-        if (B == 0) {
-            // lib.rs:313,374: no bounce, no colour -> black
-            HIP_TRY(ctx, hipMemsetAsync(w.result, 0, static_cast<size_t>(n_paths) * sizeof(float4), ctx->stream));
-        } else {
-            hipLaunchKernelGGL(k_raygen, dim3((n_paths + 255) / 256), dim3(256), 0, ctx->stream, f, sc, w.q[0], n_paths,
-                               n_pix, static_cast<unsigned long long>(s_begin) + b0, 1, counts, inline_counters(ctx));
-            HIP_TRY(ctx, hipGetLastError());
-        }
         ctx->stats.paths += n_paths;
-        for (uint32_t b = 0; b < B; ++b) {
+        // large batches run as two overlapped half-batches (not while counting: the counting kernels are slow anyway)
+        const bool overlapped = ctx->n_chains > 1 && !ctx->opt_count && B > 0 && n_paths >= (1u << 21);
+        uint64_t overlapped_segments = 0;
+        if (overlapped) {
+            rc = render_batch_overlapped(ctx, f, sc, B, n_paths, n_pix, static_cast<unsigned long long>(s_begin) + b0,
+                                         &overlapped_segments);
+            if (rc) return rc;
+        } else {
+            HIP_TRY(ctx, hipMemsetAsync(counts, 0, std::max<size_t>(counter_words, 1) * sizeof(uint32_t), ctx->stream));
+            if (B == 0) {
+                // lib.rs:313,374: no bounce, no colour -> black
+                HIP_TRY(ctx, hipMemsetAsync(w.result, 0, static_cast<size_t>(n_paths) * sizeof(float4), ctx->stream));
+            } else {
+                hipLaunchKernelGGL(k_raygen, dim3((n_paths + 255) / 256), dim3(256), 0, ctx->stream, f, sc, w.q[0], 0u, n_paths,
+                                   n_pix, static_cast<unsigned long long>(s_begin) + b0, 1, counts, inline_counters(ctx));
+                HIP_TRY(ctx, hipGetLastError());
+            }
+        }
+        for (uint32_t b = 0; b < B && !overlapped; ++b) {
             const DQueue& cur = w.q[b & 1];
             const DQueue& next = w.q[(b + 1) & 1];
             rc = launch_trace(ctx, cur, counts + b, cursors + 3 * static_cast<size_t>(b));
@@ -565,12 +588,127 @@ int render_sums_device(RtContext* ctx, const RtRenderParams* p, const Region& r,
         hipLaunchKernelGGL(k_fold, dim3((n_pix + 255) / 256), dim3(256), 0, ctx->stream, w.result, w.sums, n_pix, nb,
                            b0 == 0 ? 1 : 0);
         HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned, counts, (B + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        for (uint32_t b = 0; b < B; ++b) ctx->stats.segments += ctx->h_pinned[b];
+        if (overlapped) {
+            ctx->stats.segments += overlapped_segments;
+        } else {
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned, counts, (B + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            for (uint32_t b = 0; b < B; ++b) ctx->stats.segments += ctx->h_pinned[b];
+        }
         rc = harvest(ctx);
         if (rc) return rc;
     }
+    return RT_OK;
+}
+
+// Queue `q` seen from entry `first` on.
+DQueue queue_from(const DQueue& q, size_t first) {
+    DQueue r = q;
+    r.origin += first;
+    r.direction += first;
+    r.throughput += first;
+    r.rng += first;
+    r.slot += first;
+    r.hit_t += first;
+    r.hit_id += first;
+    return r;
+}
+
+// The same bounce loop for one batch, run as several independent chains.
+//
+// A chain of launches (trace, shade, trace, shade, ...) leaves the GPU partly idle
+// at every step: the persistent traversal kernel ends with a tail in which the last
+// waves finish their rays alone, a launch cannot begin before the previous one has
+// wholly ended, and every few bounces the host looks at a counter.  Here the batch's
+// paths are split into `n_chains` parts with queues and counters of their own, each
+// on its own stream with nothing ordering them against each other, and each chain's
+// traversal is held to its share of the compute units' wave slots so that the
+// chains' kernels are resident side by side: one chain's tails and gaps are filled
+// by the others, and memory-bound shading of one runs beside instruction-bound
+// traversal of another.  Every path is still traced and shaded by the same kernels
+// in the same order and its result lands in the slot of its number in the batch:
+// nothing changes in what is computed.
+int render_batch_overlapped(RtContext* ctx, const FrameArgs& f, const DScene& sc, uint32_t B, uint32_t n_paths,
+                            uint32_t n_pix, unsigned long long first_sample, uint64_t* segments_out) {
+    Workspace& w = ctx->ws;
+    const int K = static_cast<int>(ctx->n_chains);
+    const size_t block_words = B + 1 + 3 * static_cast<size_t>(B) + 4;
+    uint32_t n_part[kMaxChains], first_path[kMaxChains];
+    uint32_t* counts[kMaxChains];
+    uint32_t* cursors[kMaxChains];
+    DQueue q[kMaxChains][2];
+    const uint32_t share = (n_paths / static_cast<uint32_t>(K)) & ~63u;
+    for (int h = 0; h < K; ++h) {
+        first_path[h] = share * static_cast<uint32_t>(h);
+        n_part[h] = h + 1 < K ? share : n_paths - first_path[h];
+        counts[h] = w.counters + block_words * static_cast<size_t>(h);
+        cursors[h] = counts[h] + B + 1;
+        for (int k = 0; k < 2; ++k) q[h][k] = queue_from(w.q[k], first_path[h]);
+    }
+    const int shade_grid = ctx->n_cus * 8;
+    HIP_TRY(ctx, hipMemsetAsync(w.counters, 0, K * block_words * sizeof(uint32_t), ctx->chain_stream[0]));
+    HIP_TRY(ctx, hipEventRecord(ctx->chain_event[0], ctx->chain_stream[0]));
+    for (int h = 1; h < K; ++h) HIP_TRY(ctx, hipStreamWaitEvent(ctx->chain_stream[h], ctx->chain_event[0], 0));
+    for (int h = 0; h < K; ++h) {
+        hipLaunchKernelGGL(k_raygen, dim3((n_part[h] + 255) / 256), dim3(256), 0, ctx->chain_stream[h], f, sc, q[h][0],
+                           first_path[h], n_part[h], n_pix, first_sample, 1, counts[h], inline_counters(ctx));
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    ctx->wave_cap_now = std::max(8u, (32u / static_cast<uint32_t>(K)) & ~7u);
+    int rc = RT_OK;
+    bool alive[kMaxChains] = {true, true, true, true};
+    bool any_alive = true;
+    for (uint32_t b = 0; b < B && rc == RT_OK && any_alive; ++b) {
+        for (int h = 0; h < K && rc == RT_OK; ++h) {
+            if (!alive[h]) continue;
+            ctx->launch_stream = ctx->chain_stream[h];
+            rc = launch_trace(ctx, q[h][b & 1], counts[h] + b, cursors[h] + 3 * static_cast<size_t>(b));
+            if (rc != RT_OK) break;
+            ShadeArgs sa{};
+            sa.scene = sc;
+            sa.cur = q[h][b & 1];
+            sa.next = q[h][(b + 1) & 1];
+            sa.n_cur = counts[h] + b;
+            sa.n_next = counts[h] + b + 1;
+            sa.result = w.result;
+            sa.hits = ctx->d_stats;
+            sa.test_counters = inline_counters(ctx);
+            sa.last_bounce = b + 1 == B;
+            hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(256), 0, ctx->chain_stream[h], sa);
+            if (hipGetLastError() != hipSuccess) rc = fail(ctx, RT_ERR_HIP, "shade launch failed");
+        }
+        // every few bounces look whether any path is still alive
+        if (rc == RT_OK && (b & 7) == 7 && b + 1 < B) {
+            for (int h = 0; h < K; ++h)
+                if (hipMemcpyAsync(ctx->h_pinned + h, counts[h] + b + 1, sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                   ctx->chain_stream[h]) != hipSuccess)
+                    rc = fail(ctx, RT_ERR_HIP, "count read-back failed");
+            for (int h = 0; h < K; ++h)
+                if (hipStreamSynchronize(ctx->chain_stream[h]) != hipSuccess) rc = fail(ctx, RT_ERR_HIP, "stream synchronisation failed");
+            any_alive = false;
+            for (int h = 0; h < K && rc == RT_OK; ++h) {
+                alive[h] = alive[h] && ctx->h_pinned[h] != 0;
+                any_alive = any_alive || alive[h];
+            }
+        }
+    }
+    ctx->launch_stream = ctx->stream;
+    ctx->wave_cap_now = 0;
+    if (rc != RT_OK) {
+        for (int h = 0; h < K; ++h) (void)hipStreamSynchronize(ctx->chain_stream[h]);
+        return rc;
+    }
+    // the first chain's stream (the context's own) goes on once the others have finished
+    for (int h = 1; h < K; ++h) {
+        HIP_TRY(ctx, hipEventRecord(ctx->chain_event[h], ctx->chain_stream[h]));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->chain_event[h], 0));
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned, w.counters, K * block_words * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t segments = 0;
+    for (int h = 0; h < K; ++h)
+        for (uint32_t b = 0; b < B; ++b) segments += ctx->h_pinned[h * block_words + b];
+    *segments_out = segments;
     return RT_OK;
 }
 
@@ -613,6 +751,14 @@ int download_hits(RtContext* ctx, const DQueue& q, size_t n, RtHitRecord* out) {
     return RT_OK;
 }
 
+bool create_chains(RtContext* ctx) {
+    for (int h = 1; h < kMaxChains; ++h)
+        if (hipStreamCreateWithFlags(&ctx->chain_stream[h], hipStreamNonBlocking) != hipSuccess) return false;
+    for (int h = 0; h < kMaxChains; ++h)
+        if (hipEventCreateWithFlags(&ctx->chain_event[h], hipEventDisableTiming) != hipSuccess) return false;
+    return true;
+}
+
 }  // namespace
 
 // For the other translation units of this library (bvh_build.hip): record an
@@ -641,12 +787,15 @@ int rt_create(int device_ordinal, RtContext** out) {
     hipDeviceProp_t prop;
     if (hipSetDevice(device_ordinal) != hipSuccess || hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        !create_chains(ctx) ||
         hipMalloc(reinterpret_cast<void**>(&ctx->d_stats), kStatWords * sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(ctx->d_stats, 0, kStatWords * sizeof(unsigned long long)) != hipSuccess) {
         delete ctx;
         return RT_ERR_HIP;
     }
     ctx->d_inline_tests = ctx->d_stats + 7;
+    ctx->launch_stream = ctx->stream;
+    ctx->chain_stream[0] = ctx->stream;
     ctx->n_cus = prop.multiProcessorCount;
     ctx->max_grid_threads = static_cast<uint32_t>(ctx->n_cus) * 32u * kTraceBlock;  // 32 waves per CU at most
     *out = ctx;
@@ -659,7 +808,13 @@ void rt_destroy(RtContext* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_scene(ctx);
     free_workspace(ctx);
+    for (int h = 1; h < kMaxChains; ++h)
+        if (ctx->chain_stream[h]) (void)hipStreamSynchronize(ctx->chain_stream[h]);
     for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
+    for (int h = 0; h < kMaxChains; ++h)
+        if (ctx->chain_event[h]) (void)hipEventDestroy(ctx->chain_event[h]);
+    for (int h = 1; h < kMaxChains; ++h)
+        if (ctx->chain_stream[h]) (void)hipStreamDestroy(ctx->chain_stream[h]);
     (void)hipFree(ctx->d_stats);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -683,6 +838,14 @@ int rt_set_option(RtContext* ctx, uint32_t option, uint64_t value) {
             ctx->tune_phase_min = static_cast<uint32_t>(value);
             return RT_OK;
         case RT_OPT_TRACE_SHARE: ctx->tune_share = value != 0; return RT_OK;
+        case RT_OPT_TRACE_WAVES_PER_CU:
+            if (value > 32) return fail(ctx, RT_ERR_INVALID, "a compute unit holds at most 32 waves");
+            ctx->tune_waves_per_cu = static_cast<uint32_t>(value);
+            return RT_OK;
+        case RT_OPT_CHAINS:
+            if (value < 1 || value > kMaxChains) return fail(ctx, RT_ERR_INVALID, "chains per batch must be in 1..4");
+            ctx->n_chains = static_cast<uint32_t>(value);
+            return RT_OK;
         case RT_OPT_TRACE_REFILL_MIN:
             if (value < 1 || value > 64) return fail(ctx, RT_ERR_INVALID, "refill threshold must be in 1..64");
             ctx->tune_refill_min = static_cast<uint32_t>(value);
@@ -971,7 +1134,7 @@ int rt_trace_primary(RtContext* ctx, const RtRenderParams* p, uint32_t sample_in
     const FrameArgs f = frame_args(p, r);
     const uint32_t n = static_cast<uint32_t>(r.n_pixels);
     HIP_TRY(ctx, hipMemsetAsync(w.counters, 0, 8 * sizeof(uint32_t), ctx->stream));
-    hipLaunchKernelGGL(k_raygen, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, f, device_scene(ctx), w.q[0], n, n,
+    hipLaunchKernelGGL(k_raygen, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, f, device_scene(ctx), w.q[0], 0u, n, n,
                        static_cast<unsigned long long>(sample_index), jitter ? 1 : 0, w.counters, inline_counters(ctx));
     HIP_TRY(ctx, hipGetLastError());
     rc = launch_trace(ctx, w.q[0], w.counters, w.counters + 2);

@@ -79,6 +79,24 @@ def test_result_is_independent_of_batching(renderer, room):
     renderer.set_option(F.RT_OPT_TRACE_LDS_SLOTS, 8)
 
 
+def test_result_is_independent_of_the_number_of_chains(renderer, room):
+    # a batch this large is split into independent chains on separate streams
+    renderer.upload(room)
+    renderer.set_option(F.RT_OPT_SAMPLES_IN_FLIGHT, 0)
+    ref = None
+    for chains in (1, 2, 3, 4):
+        renderer.set_option(F.RT_OPT_CHAINS, chains)
+        renderer.reset_stats()
+        got = renderer.render_sums(room.params, 0, SPP)
+        st = renderer.stats()
+        if ref is None:
+            ref, ref_segments = got, st["segments"]
+        assert np.array_equal(bits(got), bits(ref)) and st["segments"] == ref_segments and st["paths"] == W * H * SPP
+    renderer.set_option(F.RT_OPT_CHAINS, 2)
+    with pytest.raises(Exception):
+        renderer.set_option(F.RT_OPT_CHAINS, 5)
+
+
 # ---------------------------------------------------------------- island-tree class
 
 @pytest.fixture(scope="module")
