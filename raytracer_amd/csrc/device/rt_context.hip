@@ -414,7 +414,7 @@ int launch_trace_variant(RtContext* ctx, TraceArgs a) {
         it = ctx->trace_occupancy.emplace(key, per_cu).first;
     }
     // share of the CU's 32 wave slots: the caller's setting, or the overlapped render loop's
-    uint32_t wave_cap = ctx->wave_cap_now ? ctx->wave_cap_now : (ctx->tune_waves_per_cu ? ctx->tune_waves_per_cu : 32u);
+    uint32_t wave_cap = ctx->tune_waves_per_cu ? ctx->tune_waves_per_cu : (ctx->wave_cap_now ? ctx->wave_cap_now : 32u);
     const uint32_t per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(static_cast<uint32_t>(it->second), wave_cap / WAVES));
     const uint32_t grid = static_cast<uint32_t>(ctx->n_cus) * per_cu;
     a.spill_stride = grid * static_cast<uint32_t>(block);
