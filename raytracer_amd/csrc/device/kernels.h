@@ -396,12 +396,11 @@ __global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num
                 pool_next += take;
             }
         }
-        if (!__any(active)) {
-            if (exhausted && pool_next == pool_end) break;
-            continue;
-        }
+        // (no `continue` on an idle wave: with nothing in hand both votes below fail by themselves,
+        // and one way round the loop keeps the loop-carried state in one set of registers)
+        if (!__any(active) && exhausted && pool_next == pool_end) break;
 
-        if (COUNT) {
+        if (COUNT && __any(active)) {
             ++w_iters;
             w_active_lanes += __popcll(__ballot(active));
         }
