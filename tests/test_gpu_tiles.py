@@ -96,3 +96,56 @@ def test_command_line_renderer_tiles_large_frames(asset_root, tmp_path):
     scene = scenes.room(asset_root, w=80, h=50, spp=4, bounces=8, incremental=2)
     cpu, _ = O.render(scene, scene.params, threads=4)
     assert a[len(b"P6\n80 50 255\n"):] == cpu.tobytes()
+
+
+def _hybrid_worker(rank, world, port, group_size, path, asset_root):
+    """One rank of the tile x sample hybrid, all ranks on GPU 0, reducing over gloo
+    through host memory (a one-GPU box has no second GPU for RCCL to reach)."""
+    import torch  # noqa: F401  (before the renderer: torch's HIP runtime must be the one loaded)
+    import torch.distributed as dist
+
+    from raytracer_amd.renderer import Renderer
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_groups = world // group_size
+    groups = [dist.new_group(list(range(g * group_size, (g + 1) * group_size))) for g in range(n_groups)]
+    mine, root = groups[rank // group_size], (rank // group_size) * group_size
+
+    def reduce_in_group(t):
+        host = t.cpu()
+        dist.reduce(host, dst=root, op=dist.ReduceOp.SUM, group=mine)
+        t.copy_(host)
+
+    scene = scenes.room(asset_root, w=72, h=48, spp=4, bounces=8)
+    p = _with(scene, 4, incremental=2)
+    with Renderer(0) as r:
+        r.upload(scene)
+        with Image(path, 72, 48) as img:
+            render_tiled(GpuTileBackend(r, torch.device("cuda", 0)), img, p, 24, 24, world=world, rank=rank,
+                         group_size=group_size, reduce_in_group=reduce_in_group if group_size > 1 else None,
+                         end_of_pass=dist.barrier)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world, group_size", [(2, 1), (2, 2), (4, 2)])
+def test_tiles_dealt_to_groups_of_ranks(asset_root, tmp_path, world, group_size):
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    path = str(tmp_path / "hybrid.ppm")
+    mp.spawn(_hybrid_worker, args=(world, port, group_size, path, asset_root), nprocs=world, join=True)
+    scene = scenes.room(asset_root, w=72, h=48, spp=4, bounces=8)
+    want, _ = O.render(scene, _with(scene, 4, incremental=2), threads=4)
+    with Image(path, 72, 48) as img:
+        got = img.pixels().copy()
+    if group_size == 1:
+        assert np.array_equal(got, want)  # tiles only: no arithmetic differs
+    else:
+        # the group's partial sums are added in another association: a truncated byte may move by one
+        assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
