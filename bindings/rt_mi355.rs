@@ -61,6 +61,9 @@ unsafe extern "C" {
     pub fn rt_build_bvh_triangles(
         ctx: *mut RtContext, shapes: *mut RtTriangle, n: u32, nodes: *mut *mut RtNode, n_nodes: *mut u32,
     ) -> c_int;
+    pub fn rt_build_bvh_spheres(
+        ctx: *mut RtContext, shapes: *mut RtSphere, n: u32, nodes: *mut *mut RtNode, n_nodes: *mut u32,
+    ) -> c_int;
     pub fn rt_free(p: *mut c_void);
 }
 

@@ -294,6 +294,10 @@ int rt_trace_rays(RtContext* ctx, const float* origins, const float* directions,
  * finite: otherwise RT_ERR_INVALID, and the family is built on the host. */
 int rt_build_bvh_triangles(RtContext* ctx, RtTriangle* shapes, uint32_t n, RtNode** nodes,
                            uint32_t* n_nodes);
+/* The same for the sphere family (boxes centre -/+ radius, /root/reference/src/shapes.rs:105-115).
+ * Planes have infinite boxes and are never split, so they need no builder. */
+int rt_build_bvh_spheres(RtContext* ctx, RtSphere* shapes, uint32_t n, RtNode** nodes,
+                         uint32_t* n_nodes);
 void rt_free(void* p);
 
 /* Device self-tests (no counterpart in the reference).  RT_SELF_TEST_DIVISION

@@ -79,7 +79,32 @@ __device__ __forceinline__ float surface_area(const float* lo, const float* hi) 
 
 // ---- per-shape bounds, root box
 
-__global__ void k_bounds(const RtTriangle* tris, uint32_t n, ShapeBounds* out, uint32_t* idx, uint32_t* root_box,
+// Centroid and box of one shape, /root/reference/src/shapes.rs:331-347 (triangle: b and c
+// rebuilt as a+e1, a+e2) and :105-115 (sphere: centre -/+ radius); false if not all finite.
+__device__ __forceinline__ bool shape_bounds(const RtTriangle& t, float* c, float* lo, float* hi) {
+    bool finite = true;
+    for (int k = 0; k < 3; ++k) {
+        const float a = t.a[k], pb = t.a[k] + t.e1[k], pc = t.a[k] + t.e2[k];
+        c[k] = a + (t.e1[k] + t.e2[k]) / 3.0f;
+        lo[k] = fminf(fminf(a, pb), pc);
+        hi[k] = fmaxf(fmaxf(a, pb), pc);
+        finite = finite && isfinite(a) && isfinite(pb) && isfinite(pc) && isfinite(c[k]);
+    }
+    return finite;
+}
+__device__ __forceinline__ bool shape_bounds(const RtSphere& s, float* c, float* lo, float* hi) {
+    bool finite = true;
+    for (int k = 0; k < 3; ++k) {
+        c[k] = s.center[k];
+        lo[k] = s.center[k] - s.radius;
+        hi[k] = s.center[k] + s.radius;
+        finite = finite && isfinite(lo[k]) && isfinite(hi[k]) && isfinite(c[k]);
+    }
+    return finite;
+}
+
+template <class Shape>
+__global__ void k_bounds(const Shape* shapes, uint32_t n, ShapeBounds* out, uint32_t* idx, uint32_t* root_box,
                          uint32_t* bad) {
     __shared__ uint32_t s_box[6];
     if (threadIdx.x < 3) s_box[threadIdx.x] = 0xFFFFFFFFu;
@@ -87,17 +112,9 @@ __global__ void k_bounds(const RtTriangle* tris, uint32_t n, ShapeBounds* out, u
     __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
-        const RtTriangle t = tris[i];
         ShapeBounds b;
         float lo[3], hi[3], c[3];
-        bool finite = true;
-        for (int k = 0; k < 3; ++k) {
-            const float a = t.a[k], pb = t.a[k] + t.e1[k], pc = t.a[k] + t.e2[k];
-            c[k] = a + (t.e1[k] + t.e2[k]) / 3.0f;
-            lo[k] = fminf(fminf(a, pb), pc);
-            hi[k] = fmaxf(fmaxf(a, pb), pc);
-            finite = finite && isfinite(a) && isfinite(pb) && isfinite(pc) && isfinite(c[k]);
-        }
+        const bool finite = shape_bounds(shapes[i], c, lo, hi);
         if (!finite) atomicAdd(bad, 1u);
         b.centroid = make_float4(c[0], c[1], c[2], 0.0f);
         b.lo = make_float4(lo[0], lo[1], lo[2], 0.0f);
@@ -389,7 +406,7 @@ __global__ void k_true_positions(const ShapeBounds* sb, const uint32_t* idx, con
 }
 
 // every misplaced false swaps with its partner; every position moves on to its child (or is finished)
-__global__ void k_swap(const ShapeBounds* sb, uint32_t* idx, const uint32_t* node_of, uint32_t* node_next, const BNode* pool,
+__global__ void k_swap(const ShapeBounds*, uint32_t* idx, const uint32_t* node_of, uint32_t* node_next, const BNode* pool,
                        uint32_t n, uint32_t n_blocks, const unsigned long long* scan, const unsigned long long* totals,
                        const uint32_t* true_pos) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -406,9 +423,11 @@ __global__ void k_swap(const ShapeBounds* sb, uint32_t* idx, const uint32_t* nod
     }
     const uint32_t child = nd.child0 + (i >= nd.mid ? 1u : 0u);
     node_next[i] = pool[child].slot != kNone ? child : kNone;
-    if (misplaced(sb, idx, node_of, pool, i) & 0xFFFFFFFFull) {
-        const uint32_t j = static_cast<uint32_t>(scan_at(scan, totals, n, n_blocks, i)) -
-                           static_cast<uint32_t>(scan_at(scan, totals, n, n_blocks, nd.first));
+    // (whether this position holds a misplaced false is read off the prefix sums, not recomputed
+    // from idx[], which other threads of this launch are exchanging)
+    const uint32_t here = static_cast<uint32_t>(scan_at(scan, totals, n, n_blocks, i));
+    if (static_cast<uint32_t>(scan_at(scan, totals, n, n_blocks, i + 1)) != here) {
+        const uint32_t j = here - static_cast<uint32_t>(scan_at(scan, totals, n, n_blocks, nd.first));
         const uint32_t t_first = static_cast<uint32_t>(scan_at(scan, totals, n, n_blocks, nd.first) >> 32);
         const uint32_t t_end = static_cast<uint32_t>(scan_at(scan, totals, n, n_blocks, nd.first + nd.count) >> 32);
         const uint32_t partner = true_pos[t_first + (t_end - t_first - 1u - j)];  // j-th from the back
@@ -454,7 +473,10 @@ int rt_context_device(RtContext* ctx, hipStream_t* stream);
         }                                                                                                      \
     } while (0)
 
-extern "C" int rt_build_bvh_triangles(RtContext* ctx, RtTriangle* shapes, uint32_t n, RtNode** nodes_out, uint32_t* n_nodes) {
+namespace {
+
+template <class Shape>
+int build_bvh_on_gpu(RtContext* ctx, Shape* shapes, uint32_t n, RtNode** nodes_out, uint32_t* n_nodes) {
     using namespace rtb;
     if (!ctx || !nodes_out || !n_nodes || (n && !shapes)) return RT_ERR_INVALID;
     *nodes_out = nullptr;
@@ -462,7 +484,7 @@ extern "C" int rt_build_bvh_triangles(RtContext* ctx, RtTriangle* shapes, uint32
     hipStream_t stream = nullptr;
     int rc = rt_context_device(ctx, &stream);
     if (rc) return rc;
-    if (n > 0x07FFFFFFu) return rt_context_fail(ctx, RT_ERR_INVALID, "too many triangles");
+    if (n > 0x07FFFFFFu) return rt_context_fail(ctx, RT_ERR_INVALID, "too many shapes");
 
     std::vector<BNode> pool_h;
     std::vector<uint32_t> idx_h(n);
@@ -476,7 +498,7 @@ extern "C" int rt_build_bvh_triangles(RtContext* ctx, RtTriangle* shapes, uint32
         pool_h.push_back(r);
     } else {
         DeviceBuffers mem;
-        RtTriangle* d_tris;
+        Shape* d_tris;
         ShapeBounds* d_sb;
         uint32_t *d_idx, *d_node[2], *d_active[2], *d_bins, *d_counters, *d_root, *d_true_pos;
         BNode* d_pool;
@@ -499,19 +521,20 @@ extern "C" int rt_build_bvh_triangles(RtContext* ctx, RtTriangle* shapes, uint32
         BVH_TRY(mem.alloc(&d_totals, n_blocks + 1));
         BVH_TRY(mem.alloc(&d_bins, static_cast<size_t>(max_active) * kNodeBinWords));
 
-        BVH_TRY(hipMemcpyAsync(d_tris, shapes, static_cast<size_t>(n) * sizeof(RtTriangle), hipMemcpyHostToDevice, stream));
+        BVH_TRY(hipMemcpyAsync(d_tris, shapes, static_cast<size_t>(n) * sizeof(Shape), hipMemcpyHostToDevice, stream));
         const uint32_t root_init[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u};  // [6] = non-finite shapes
         BVH_TRY(hipMemcpyAsync(d_root, root_init, sizeof root_init, hipMemcpyHostToDevice, stream));
         BVH_TRY(hipMemsetAsync(d_counters, 0, 4 * sizeof(uint32_t), stream));
         const dim3 per_shape((n + 255) / 256), block(256);
-        hipLaunchKernelGGL(k_bounds, per_shape, block, 0, stream, d_tris, n, d_sb, d_idx, d_root, d_root + 6);
+        hipLaunchKernelGGL(k_bounds<Shape>, per_shape, block, 0, stream, static_cast<const Shape*>(d_tris), n, d_sb, d_idx, d_root,
+                           d_root + 6);
         hipLaunchKernelGGL(k_root, per_shape, block, 0, stream, d_root, n, d_pool, d_node[0], d_active[0], d_counters);
         BVH_TRY(hipGetLastError());
         uint32_t h[8];
         BVH_TRY(hipMemcpyAsync(h, d_root, sizeof h, hipMemcpyDeviceToHost, stream));
         BVH_TRY(hipStreamSynchronize(stream));
         if (h[6] != 0)
-            return rt_context_fail(ctx, RT_ERR_INVALID, "non-finite triangle coordinates: build this family on the host");
+            return rt_context_fail(ctx, RT_ERR_INVALID, "non-finite coordinates: build this family on the host");
 
         uint32_t n_active = n >= kMinSplit ? 1u : 0u;
         int cur = 0;
@@ -572,13 +595,23 @@ extern "C" int rt_build_bvh_triangles(RtContext* ctx, RtTriangle* shapes, uint32
     }
     // the in-place permutation of config.rs:113-134
     if (n) {
-        std::vector<RtTriangle> moved(n);
+        std::vector<Shape> moved(n);
         for (uint32_t i = 0; i < n; ++i) moved[i] = shapes[idx_h[i]];
-        std::memcpy(shapes, moved.data(), static_cast<size_t>(n) * sizeof(RtTriangle));
+        std::memcpy(shapes, moved.data(), static_cast<size_t>(n) * sizeof(Shape));
     }
     *nodes_out = out;
     *n_nodes = total;
     return RT_OK;
+}
+
+}  // namespace
+
+extern "C" int rt_build_bvh_triangles(RtContext* ctx, RtTriangle* shapes, uint32_t n, RtNode** nodes, uint32_t* n_nodes) {
+    return build_bvh_on_gpu(ctx, shapes, n, nodes, n_nodes);
+}
+
+extern "C" int rt_build_bvh_spheres(RtContext* ctx, RtSphere* shapes, uint32_t n, RtNode** nodes, uint32_t* n_nodes) {
+    return build_bvh_on_gpu(ctx, shapes, n, nodes, n_nodes);
 }
 
 extern "C" void rt_free(void* p) { std::free(p); }

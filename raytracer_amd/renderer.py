@@ -64,12 +64,22 @@ class Renderer:
     def build_bvh_triangles(self, triangles: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
         """`BvhNode::new` (/root/reference/src/bvh.rs:48) for triangles, on the GPU.
         Returns (nodes, triangles in post-build order); the input is not modified."""
-        from .scene import NODE_DT, TRIANGLE_DT
+        from .scene import TRIANGLE_DT
 
-        tris = np.ascontiguousarray(triangles, dtype=TRIANGLE_DT).copy()
+        return self._build_bvh(self._lib.rt_build_bvh_triangles, triangles, TRIANGLE_DT)
+
+    def build_bvh_spheres(self, spheres: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+        """The same for spheres."""
+        from .scene import SPHERE_DT
+
+        return self._build_bvh(self._lib.rt_build_bvh_spheres, spheres, SPHERE_DT)
+
+    def _build_bvh(self, fn, shapes, dtype):
+        from .scene import NODE_DT
+
+        tris = np.ascontiguousarray(shapes, dtype=dtype).copy()
         raw, n_nodes = C.c_void_p(), F.u32(0)
-        self._check(self._lib.rt_build_bvh_triangles(self._ctx, tris.ctypes.data if tris.size else None, tris.size,
-                                                     C.byref(raw), C.byref(n_nodes)))
+        self._check(fn(self._ctx, tris.ctypes.data if tris.size else None, tris.size, C.byref(raw), C.byref(n_nodes)))
         try:
             buf = (C.c_char * (n_nodes.value * NODE_DT.itemsize)).from_address(raw.value)
             nodes = np.frombuffer(buf, dtype=NODE_DT, count=n_nodes.value).copy()

@@ -154,6 +154,16 @@ def render_tiled(backend: TileBackend, image: Image, params, tile_w: int, tile_h
     # that the GPU renders tile i while tile i-1 is written and tile i+1 is read
     # (the copies are plain memcpy over up to hundreds of MB of page cache).
     copier = ThreadPoolExecutor(max_workers=1)
+    try:
+        _render_passes(backend, image, params, grid, mine, copier, chunk, n_passes, running, first_pass, rank, group_size,
+                       member, reduce_in_group, end_of_pass, progress)
+    finally:
+        copier.shutdown()
+    image.flush()
+
+
+def _render_passes(backend, image, params, grid, mine, copier, chunk, n_passes, running, first_pass, rank, group_size,
+                   member, reduce_in_group, end_of_pass, progress) -> None:
     for p in range(n_passes):
         k = p + first_pass
         if group_size == 1:
@@ -189,8 +199,6 @@ def render_tiled(backend: TileBackend, image: Image, params, tile_w: int, tile_h
             end_of_pass()
         if progress is not None and rank == 0:
             progress(first_pass + (p + 1) * chunk)
-    copier.shutdown()
-    image.flush()
 
 
 class GpuTileBackend:

@@ -128,3 +128,21 @@ def test_scene_parsed_with_the_gpu_builder_equals_the_host_parse(renderer, asset
     a, b = parse(text, asset_root), parse(text, asset_root, renderer=renderer)
     assert_same_tree(b.triangle_nodes, b.triangles, a.triangle_nodes, a.triangles)
     assert a.sphere_nodes.tobytes() == b.sphere_nodes.tobytes() and a.materials.tobytes() == b.materials.tobytes()
+
+
+def test_sphere_family(renderer):
+    from raytracer_amd.scene import SPHERE_DT
+    lib = F.host_lib()
+    for n in (0, 5, 8, 300, 20000):
+        rng = np.random.default_rng(n + 1)
+        sp = np.zeros(n, dtype=SPHERE_DT)
+        sp["center"] = rng.uniform(-10, 10, size=(n, 3))
+        sp["radius"] = rng.uniform(0.01, 0.5, size=n)
+        sp["material"] = np.arange(n) % 5
+        host = sp.copy()
+        cnt = F.u32(0)
+        raw = lib.rth_build_bvh_spheres(host.ctypes.data if n else None, n, C.byref(cnt))
+        buf = (C.c_char * (cnt.value * NODE_DT.itemsize)).from_address(raw)
+        cpu_nodes = np.frombuffer(buf, dtype=NODE_DT, count=cnt.value).copy()
+        lib.rth_free(raw)
+        assert_same_tree(*renderer.build_bvh_spheres(sp), cpu_nodes, host)
