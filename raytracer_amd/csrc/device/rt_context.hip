@@ -43,8 +43,8 @@ struct Workspace {
     float* sums = nullptr;
     uint8_t* rgb8 = nullptr;
     uint32_t* counters = nullptr;  // [0..B] queue lengths, then 3 cursors per bounce
-    uint2* spill = nullptr;
-    size_t spill_entries = 0;
+    uint2* spill = nullptr;      // kMaxChains areas of spill_entries each: traversal launches of different chains run side by side
+    size_t spill_entries = 0;    // entries of one area
 };
 
 }  // namespace
@@ -56,6 +56,7 @@ struct RtContext {
     hipStream_t chain_stream[4] = {nullptr, nullptr, nullptr, nullptr};  // [0] = stream; the others carry further chains of a batch
     hipEvent_t chain_event[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t launch_stream = nullptr;  // where traversal launches go (stream, or a chain's stream)
+    uint32_t launch_chain = 0;            // ... and which chain's stack overflow area they use
     uint32_t wave_cap_now = 0;            // traversal waves per CU while chains run side by side (0 = no cap)
     uint32_t n_chains = 2;                // independent chains a large batch is split into (1 = none)
     std::string error;
@@ -450,7 +451,7 @@ int launch_trace(RtContext* ctx, const DQueue& q, const uint32_t* n_rays, uint32
         a.q = q;
         a.n_rays = n_rays;
         a.cursor = cursors + kind;
-        a.spill = ctx->ws.spill;
+        a.spill = ctx->ws.spill + ctx->ws.spill_entries * ctx->launch_chain;
         a.lds_slots = ctx->tune_lds_slots;
         a.phase_min = ctx->tune_phase_min;
         a.chunk_max = ctx->tune_chunk_max;
@@ -669,6 +670,7 @@ int render_batch_overlapped(RtContext* ctx, const FrameArgs& f, const DScene& sc
         for (int h = 0; h < K && rc == RT_OK; ++h) {
             if (!alive[h]) continue;
             ctx->launch_stream = ctx->chain_stream[h];
+            ctx->launch_chain = static_cast<uint32_t>(h);
             rc = launch_trace(ctx, q[h][b & 1], counts[h] + b, cursors[h] + 3 * static_cast<size_t>(b));
             if (rc != RT_OK) break;
             ShadeArgs sa{};
@@ -700,6 +702,7 @@ int render_batch_overlapped(RtContext* ctx, const FrameArgs& f, const DScene& sc
         }
     }
     ctx->launch_stream = ctx->stream;
+    ctx->launch_chain = 0;
     ctx->wave_cap_now = 0;
     if (rc != RT_OK) {
         for (int h = 0; h < K; ++h) (void)hipStreamSynchronize(ctx->chain_stream[h]);
@@ -1046,7 +1049,7 @@ int rt_upload_scene(RtContext* ctx, const RtSceneDesc* s) {
             (void)hipFree(w.spill);
             w.spill = nullptr;
             w.spill_entries = 0;
-            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&w.spill), entries * sizeof(uint2)));
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&w.spill), kMaxChains * entries * sizeof(uint2)));
             w.spill_entries = entries;
         }
     }

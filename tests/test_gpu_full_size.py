@@ -80,21 +80,30 @@ def test_result_is_independent_of_batching(renderer, room):
 
 
 def test_result_is_independent_of_the_number_of_chains(renderer, room):
-    # a batch this large is split into independent chains on separate streams
+    # A batch this large is split into independent chains on separate streams whose kernels run
+    # side by side; enough paths (33 M) that they really do overlap for most of the render, so
+    # that anything the chains wrongly share (the stack overflow area once was) shows.
     renderer.upload(room)
     renderer.set_option(F.RT_OPT_SAMPLES_IN_FLIGHT, 0)
     ref = None
-    for chains in (1, 2, 3, 4):
+    for chains in (1, 2, 2, 3, 4):
         renderer.set_option(F.RT_OPT_CHAINS, chains)
         renderer.reset_stats()
-        got = renderer.render_sums(room.params, 0, SPP)
+        got = renderer.render_sums(room.params, 0, 16)
         st = renderer.stats()
         if ref is None:
             ref, ref_segments = got, st["segments"]
-        assert np.array_equal(bits(got), bits(ref)) and st["segments"] == ref_segments and st["paths"] == W * H * SPP
+        assert np.array_equal(bits(got), bits(ref)), f"{chains} chains: {np.count_nonzero(bits(got) != bits(ref))} values differ"
+        assert st["segments"] == ref_segments and st["paths"] == W * H * 16
     renderer.set_option(F.RT_OPT_CHAINS, 2)
     with pytest.raises(Exception):
         renderer.set_option(F.RT_OPT_CHAINS, 5)
+    # and against the oracle: tiles of the 16-sample frame rendered with two chains
+    got = renderer.render_sums(room.params, 0, 16)
+    for x0, y0 in ((100, 900), (1500, 300)):
+        p = room.params.copy()
+        p.tile_x, p.tile_y, p.tile_w, p.tile_h = x0, y0, 64, 36
+        assert np.array_equal(bits(got[y0:y0 + 36, x0:x0 + 64]), bits(O.render_sums(room, p, 0, 16, threads=8)))
 
 
 # ---------------------------------------------------------------- island-tree class
