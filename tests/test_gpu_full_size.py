@@ -106,6 +106,27 @@ def test_result_is_independent_of_the_number_of_chains(renderer, room):
         assert np.array_equal(bits(got[y0:y0 + 36, x0:x0 + 64]), bits(O.render_sums(room, p, 0, 16, threads=8)))
 
 
+def test_one_large_batch_equals_many_small_ones(renderer, room):
+    # 128 samples as one batch of 2.7e8 paths in two chains (the default for a frame this size)
+    # against sixteen batches of 8 samples in one chain: the same left fold over the same samples
+    renderer.upload(room)
+    renderer.set_option(F.RT_OPT_SAMPLES_IN_FLIGHT, 0)
+    renderer.set_option(F.RT_OPT_CHAINS, 2)
+    renderer.reset_stats()
+    big = renderer.render_sums(room.params, 7, 128)
+    big_stats = renderer.stats()
+    renderer.set_option(F.RT_OPT_SAMPLES_IN_FLIGHT, 8)
+    renderer.set_option(F.RT_OPT_CHAINS, 1)
+    renderer.reset_stats()
+    small = renderer.render_sums(room.params, 7, 128)
+    small_stats = renderer.stats()
+    renderer.set_option(F.RT_OPT_SAMPLES_IN_FLIGHT, 0)
+    renderer.set_option(F.RT_OPT_CHAINS, 2)
+    assert np.array_equal(bits(big), bits(small))
+    assert big_stats["segments"] == small_stats["segments"] and big_stats["hits"] == small_stats["hits"]
+    assert big_stats["paths"] == W * H * 128
+
+
 # ---------------------------------------------------------------- island-tree class
 
 @pytest.fixture(scope="module")
