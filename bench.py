@@ -152,6 +152,7 @@ def main() -> None:
     ap.add_argument("--detail", type=int, default=4, help="size of the generated scene (4 = 2.9e5 / 8.2e4 / 1.0e6 triangles)")
     ap.add_argument("--tile", type=int, default=4096, help="tile edge of the room16k workload")
     ap.add_argument("--trace-waves-per-cu", type=int, default=0, help="cap on resident traversal waves per CU (0 = automatic)")
+    ap.add_argument("--shade-groups", type=int, default=None, help="shading workgroups per CU (library default: 8)")
     ap.add_argument("--chains", type=int, default=None, help="independent chains a batch is split into (library default: 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -200,6 +201,8 @@ def main() -> None:
     chains = 2 if args.chains is None else args.chains  # 2 is the library's default
     r.set_option(F.RT_OPT_CHAINS, chains)
     r.set_option(F.RT_OPT_TRACE_WAVES_PER_CU, args.trace_waves_per_cu)
+    if args.shade_groups is not None:
+        r.set_option(F.RT_OPT_SHADE_GROUPS_PER_CU, args.shade_groups)
     params = scene.params
     tiled = args.workload == "room16k"
     count_params = params

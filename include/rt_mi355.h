@@ -224,6 +224,7 @@ typedef enum RtOption {
     RT_OPT_TRACE_CACHE_NODES = 10, /* top-of-tree branch records a multi-wave workgroup keeps in LDS (0..2048) */
     RT_OPT_TRACE_REFILL_MIN = 11, /* idle lanes of a wave that trigger a refill from the queue (1..64) */
     RT_OPT_CHAINS = 13,         /* 1..4: independent chains (own queues, own stream) a large batch of paths is split into; each chain's tails and launch gaps are filled by the others (default 2) */
+    RT_OPT_SHADE_GROUPS_PER_CU = 14, /* grid of the shading kernel: workgroups of 256 threads per compute unit (1..64, default 8) */
     RT_OPT_TRACE_WAVES_PER_CU = 12 /* traversal waves resident per compute unit (0 = as many as fit, else 1..32): leaves room for kernels of another context on the same GPU */
 } RtOption;
 

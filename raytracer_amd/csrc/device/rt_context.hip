@@ -58,6 +58,7 @@ struct RtContext {
     hipStream_t launch_stream = nullptr;  // where traversal launches go (stream, or a chain's stream)
     uint32_t launch_chain = 0;            // ... and which chain's stack overflow area they use
     uint32_t wave_cap_now = 0;            // traversal waves per CU while chains run side by side (0 = no cap)
+    uint32_t tune_shade_groups = 8;       // shading workgroups (256 threads) per compute unit
     uint32_t n_chains = 2;                // independent chains a large batch is split into (1 = none)
     std::string error;
 
@@ -545,7 +546,7 @@ int render_sums_device(RtContext* ctx, const RtRenderParams* p, const Region& r,
     uint32_t* counts = w.counters;           // [0..B]
     uint32_t* cursors = w.counters + B + 1;  // [B][3]
     const size_t counter_words = B + 1 + 3 * static_cast<size_t>(B);
-    const int shade_grid = ctx->n_cus * 8;
+    const int shade_grid = ctx->n_cus * static_cast<int>(ctx->tune_shade_groups);
 
     for (uint32_t b0 = 0; b0 < count; b0 += static_cast<uint32_t>(S)) {
         const uint32_t nb = std::min<uint32_t>(static_cast<uint32_t>(S), count - b0);
@@ -653,7 +654,7 @@ int render_batch_overlapped(RtContext* ctx, const FrameArgs& f, const DScene& sc
         cursors[h] = counts[h] + B + 1;
         for (int k = 0; k < 2; ++k) q[h][k] = queue_from(w.q[k], first_path[h]);
     }
-    const int shade_grid = ctx->n_cus * 8;
+    const int shade_grid = ctx->n_cus * static_cast<int>(ctx->tune_shade_groups);
     HIP_TRY(ctx, hipMemsetAsync(w.counters, 0, K * block_words * sizeof(uint32_t), ctx->chain_stream[0]));
     HIP_TRY(ctx, hipEventRecord(ctx->chain_event[0], ctx->chain_stream[0]));
     for (int h = 1; h < K; ++h) HIP_TRY(ctx, hipStreamWaitEvent(ctx->chain_stream[h], ctx->chain_event[0], 0));
@@ -851,6 +852,10 @@ int rt_set_option(RtContext* ctx, uint32_t option, uint64_t value) {
         case RT_OPT_TRACE_WAVES_PER_CU:
             if (value > 32) return fail(ctx, RT_ERR_INVALID, "a compute unit holds at most 32 waves");
             ctx->tune_waves_per_cu = static_cast<uint32_t>(value);
+            return RT_OK;
+        case RT_OPT_SHADE_GROUPS_PER_CU:
+            if (value < 1 || value > 64) return fail(ctx, RT_ERR_INVALID, "shading workgroups per CU must be in 1..64");
+            ctx->tune_shade_groups = static_cast<uint32_t>(value);
             return RT_OK;
         case RT_OPT_CHAINS:
             if (value < 1 || value > kMaxChains) return fail(ctx, RT_ERR_INVALID, "chains per batch must be in 1..4");
