@@ -353,8 +353,8 @@ __global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num
             if (item == kItemNone) {
                 // bvh.rs:300 + lib.rs:333: keep the earlier family on equal distance.
                 if (best_t < prior_t) {
-                    a.q.hit_t[ray] = best_t;
-                    a.q.hit_id[ray] = (static_cast<uint32_t>(KIND) << kHitKindShift) | best_i;
+                    stream_store(&a.q.hit_t[ray], best_t);
+                    stream_store(&a.q.hit_id[ray], (static_cast<uint32_t>(KIND) << kHitKindShift) | best_i);
                 }
                 active = false;
             }
@@ -381,9 +381,9 @@ __global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num
                 if (!active && rank < take) {
                     const uint32_t idx = pool_next + rank;
                     ray = idx;
-                    o = f3(a.q.origin[idx]);
-                    d = f3(a.q.direction[idx]);
-                    prior_t = a.q.hit_t[idx];
+                    o = f3(stream_load(&a.q.origin[idx]));  // read once: kept out of the way of the node data in the caches
+                    d = f3(stream_load(&a.q.direction[idx]));
+                    prior_t = stream_load(&a.q.hit_t[idx]);
                     best_t = kInfinity;
                     best_i = kHitNone;
                     sp = 0;
