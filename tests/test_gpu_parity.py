@@ -327,3 +327,35 @@ def test_errors_are_reported_not_fatal(renderer):
         p.tile_x, p.tile_w, p.tile_h = 10, 10, 4
         with pytest.raises(RtError):
             r.render_sums(p, 0, 1)
+
+
+@pytest.mark.parametrize("which", ["room", "tree", "materials"])
+def test_random_views(renderer, asset_root, which):
+    """Cameras at random places (inside furniture, grazing walls, looking away from the scene):
+    radiance and counters still equal the oracle's bit for bit."""
+    base = {"room": lambda: scenes.room(asset_root, w=40, h=24, spp=2, bounces=14),
+            "tree": lambda: scenes.tree(asset_root, w=40, h=24, spp=2, bounces=14),
+            "materials": lambda: scenes.materials(w=40, h=24, spp=2, bounces=14)}[which]()
+    renderer.upload(base)
+    rng = np.random.default_rng({"room": 1, "tree": 2, "materials": 3}[which])
+    for _ in range(6):
+        p = base.params.copy()
+        cam = rng.uniform(-2.5, 2.5, 3) + np.array([0.0, 1.5, 0.0])
+        look = rng.normal(size=3)
+        look /= np.linalg.norm(look)
+        right = np.cross(look, [0.0, 1.0, 0.0])
+        right = right / np.linalg.norm(right) if np.linalg.norm(right) > 1e-3 else np.array([1.0, 0.0, 0.0])
+        up = np.cross(right, look)
+        centre = cam + look
+        p.camera[:] = [float(v) for v in cam]
+        p.top_edge[:] = [float(v) for v in right * 1.6]
+        p.left_edge[:] = [float(v) for v in -up * 0.96]
+        p.top_left[:] = [float(v) for v in centre - right * 0.8 + up * 0.48]
+        renderer.reset_stats()
+        c = O.OracleCounters()
+        cpu = O.render_sums(base, p, 0, 2, threads=4, counters=c)
+        gpu = renderer.render_sums(p, 0, 2)
+        assert np.array_equal(bits(gpu), bits(cpu))
+        s = renderer.stats()
+        assert s["segments"] == c.segments and s["hits"] == c.hits
+        assert_hits_equal(renderer.trace_primary(p, 0, True), O.trace_primary(base, p, 0, True))
