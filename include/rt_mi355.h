@@ -305,8 +305,11 @@ void rt_free(void* p);
  * checks, on about `n_cases` operand pairs, that the traversal kernel's
  * shared-reciprocal division returns exactly the bits of an IEEE division over
  * the whole operand range it is used for; `failures` receives the number of
- * differing quotients (0 on a correct build). */
+ * differing quotients (0 on a correct build).  RT_SELF_TEST_RECIPROCAL does the
+ * same for the triangle test's reciprocal of the determinant, exhaustively
+ * (every binary32 value in its range; `n_cases` is ignored). */
 #define RT_SELF_TEST_DIVISION 1u
+#define RT_SELF_TEST_RECIPROCAL 2u
 int rt_self_test(RtContext* ctx, uint32_t which, uint64_t n_cases, uint64_t* failures);
 
 int rt_get_stats(RtContext* ctx, RtStats* out);

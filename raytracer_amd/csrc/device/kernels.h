@@ -118,52 +118,97 @@ __device__ __forceinline__ bool plane_hit(const DPlane& p, F3 o, F3 d, float& t)
 // the same answer (a failed earlier test makes the result false whatever the
 // later values, NaN or infinite, turn out to be) without branches inside a step
 // that other lanes of the wave are executing anyway.
-__device__ __forceinline__ bool triangle_hit(F3 a, F3 e1, F3 e2, F3 o, F3 d, float& t) {
-    const F3 h = cross(d, e2);
-    const float det = dot(e1, h);
-    const float inv = 1.0f / det;
+//
+// The two cross products h = d x e2 and q = (o - a) x e1 and the four dot
+// products run two at a time in packed instructions (v_pk_mul_f32 /
+// v_pk_add_f32: two binary32 operations per lane, each rounded exactly like its
+// scalar form; nothing is fused): ex/ey/ez hold (e2, e1) of one axis, so the
+// first half of every pair below belongs to h and the second to q.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// 1.0f / b for |b| in [2^-20, 2^60): hipcc expands a correctly rounded division
+// into v_div_scale (both operands), a reciprocal refined by one Newton step,
+// the quotient refined by two residual steps, v_div_fmas and v_div_fixup.  With
+// numerator 1 and b in this range nothing is scaled and no special case
+// applies, so the seven instructions below are the same operations on the same
+// values, hence the same bits (k_selftest_reciprocal compares all of them).
+constexpr float kRcpLo = 0x1p-20f, kRcpHi = 0x1p60f;
+__device__ __forceinline__ float rcp_midrange(float b) {
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    const float r = __builtin_fmaf(__builtin_fmaf(-b, r0, 1.0f), r0, r0);
+    const float q = __builtin_fmaf(__builtin_fmaf(-b, r, 1.0f), r, r);
+    return __builtin_fmaf(__builtin_fmaf(-b, q, 1.0f), r, q);
+}
+
+__device__ __forceinline__ v2f swapped(v2f v) { return __builtin_shufflevector(v, v, 1, 0); }
+__device__ __forceinline__ bool triangle_hit(v2f ex, v2f ey, v2f ez, F3 a, F3 o, F3 d, float& t) {
     const F3 s = o - a;
-    const float u = inv * dot(s, h);
-    const F3 q = cross(s, e1);
-    const float v = inv * dot(d, q);
-    t = inv * dot(e2, q);
+    const v2f px = {d.x, s.x}, py = {d.y, s.y}, pz = {d.z, s.z};
+    const v2f cx = py * ez - pz * ey;  // (h.x, q.x)
+    const v2f cy = pz * ex - px * ez;  // (h.y, q.y)
+    const v2f cz = px * ey - py * ex;  // (h.z, q.z)
+    const v2f qhx = swapped(cx), qhy = swapped(cy), qhz = swapped(cz);
+    const v2f t_det = (ex * qhx + ey * qhy) + ez * qhz;  // (dot(e2, q), dot(e1, h))
+    v2f v_u = (px * qhx + py * qhy) + pz * qhz;          // (dot(d, q), dot(s, h))
+    asm volatile("" : "+v"(v_u));  // keeps the packed sums above the branch below (sunk past it, they lose their operand selects)
+    const float det = t_det.y;
+    // A determinant below 2e-6 fails the test whatever `inv` is, so only large
+    // (or NaN) determinants need the general division; the choice is made for
+    // the whole wave, so the common case runs no division at all.
+    static_assert(kRcpLo < 2e-6f, "every determinant that can pass must be in the reciprocal's range");
+    const float inv = __any(!(fabsf(det) < kRcpHi)) ? 1.0f / det : rcp_midrange(det);
+    const v2f vu = v2f{inv, inv} * v_u;
+    const float u = vu.y, v = vu.x;
+    t = inv * t_det.x;
     const bool ok_det = !(fabsf(det) < 2e-6f);
     const bool ok_u = u >= 0.0f && u <= 1.0f;
     const bool ok_v = !(v < 0.0f || u + v > 1.0f);
     return ok_det & ok_u & ok_v & (t > kMinDistance);
 }
+__device__ __forceinline__ bool triangle_hit(const DTriangle* tri, F3 o, F3 d, float& t) {
+    const float4* tp = reinterpret_cast<const float4*>(tri);
+    const float4 v0 = tp[0], v1 = tp[1];
+    const float az = tri->a[2];
+    return triangle_hit(v2f{v0.x, v0.y}, v2f{v0.z, v0.w}, v2f{v1.x, v1.y}, f3(v1.z, v1.w, az), o, d, t);
+}
 
 // ------------------------------------------------------------------- trace
 
-// Exact division for the slab test at less than half the cost of `/`.
+// Exact division for the slab test at about a third of the cost of `/`.
 //
-// hipcc expands a correctly rounded `a / b` into: scale both operands
-// (v_div_scale), r = rcp(b) refined by one Newton step, q = a*r refined by two
-// residual steps, then v_div_fmas / v_div_fixup for the scaled and special
-// cases — eleven instructions, four of which depend on b alone.  The slab test
-// divides twelve differences by the same three direction components per node,
-// so the reciprocal part is computed once per ray (refine_rcp) and each quotient
-// costs a multiply and four FMAs (div_by2).  When no operand needs scaling this
-// is the very same operation sequence, hence the same bits.  The caller
-// guarantees that regime (see `fast` in k_trace): |b| in [2^-30, 2],
-// a == 0 or |a| in [2^-84, 2^60); anything else takes the plain `/`.
-// A zero quotient may come out with either sign; the slab test only compares.
-__device__ __forceinline__ float refine_rcp(float b) {
-    const float r0 = __builtin_amdgcn_rcpf(b);
-    const float e = __builtin_fmaf(-b, r0, 1.0f);
-    return __builtin_fmaf(e, r0, r0);
+// The slab test divides twelve differences by the same three direction
+// components per node, and the reference's results depend on every quotient
+// being the correctly rounded one.  hipcc expands `a / b` into eleven
+// instructions; here the divisor's part is done once per ray and a quotient
+// costs a multiply and three FMAs:
+//   per ray   zh = RN(1/b) (one IEEE division), zl = RN((1 - b*zh) * zh), so that
+//             zh + zl is 1/b to about 46 bits;
+//   quotient  q0 = RN(a*zh + RN(a*zl))     within 1/2 ulp + 2^-22 ulp of a/b, i.e.
+//                                          one of the two neighbours of a/b,
+//             r  = a - b*q0                exact in one FMA for such a q0,
+//             q  = RN(q0 + r*zh)           = RN(a/b): Markstein's theorem (a
+//                                          correctly rounded reciprocal corrects a
+//                                          faithful quotient to the correctly
+//                                          rounded one).
+// This holds while nothing under- or overflows on the way; the caller guarantees
+// |b| in [2^-30, 2], a == 0 or |a| in [2^-84, 2^60) (see `fast` in k_trace) and
+// takes the plain `/` otherwise.  A zero quotient may come out with either sign;
+// the slab test only compares.  k_selftest_division compares with `/`.
+struct Reciprocal {
+    float hi, lo;
+};
+__device__ __forceinline__ Reciprocal reciprocal_of(float b) {
+    const float zh = 1.0f / b;
+    return Reciprocal{zh, __builtin_fmaf(-b, zh, 1.0f) * zh};
 }
 // Two quotients with a common divisor in one packed instruction stream
 // (v_pk_mul_f32 / v_pk_fma_f32 carry two binary32 operations per lane, each
 // rounded exactly like its scalar form).
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f div_by2(v2f a, float b, float r) {
-    const v2f nb = {-b, -b}, rr = {r, r};
-    v2f q = a * rr;
-    v2f e = __builtin_elementwise_fma(nb, q, a);
-    q = __builtin_elementwise_fma(e, rr, q);
-    e = __builtin_elementwise_fma(nb, q, a);
-    return __builtin_elementwise_fma(e, rr, q);
+__device__ __forceinline__ v2f div_by2(v2f a, float b, Reciprocal z) {
+    const v2f nb = {-b, -b}, hh = {z.hi, z.hi}, ll = {z.lo, z.lo};
+    const v2f q = __builtin_elementwise_fma(a, hh, a * ll);
+    const v2f r = __builtin_elementwise_fma(nb, q, a);
+    return __builtin_elementwise_fma(r, hh, q);
 }
 
 // True when |v| is in [lo, hi) — false for NaN.
@@ -228,6 +273,16 @@ template <int CTRL, int ROW_MASK>
 __device__ inline uint32_t dpp_or_zero(uint32_t v) {
     return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, ROW_MASK, 0xf, false));
 }
+// Number of set bits of `mask` below this lane (one v_mbcnt pair, no per-lane mask to keep).
+__device__ __forceinline__ uint32_t bits_below_lane(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+}
+// Value of `v` in lane `src` (0..63) of this wave.
+__device__ __forceinline__ uint32_t from_lane(uint32_t v, uint32_t src) {
+    return static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>(src << 2), static_cast<int>(v)));
+}
+__device__ __forceinline__ float from_lane(float v, uint32_t src) { return __uint_as_float(from_lane(__float_as_uint(v), src)); }
+
 __device__ inline uint32_t wave_scan_add(uint32_t v) {
     v += dpp_or_zero<0x111, 0xf>(v);  // row_shr:1
     v += dpp_or_zero<0x112, 0xf>(v);  // row_shr:2
@@ -282,7 +337,7 @@ __host__ __device__ inline size_t trace_lds_per_wave(uint32_t lds_slots) {
 // Eight waves per SIMD leave each wave 96 scalar registers, of which the
 // system's trap handler keeps 16: the kernel is held to the 80 that remain.
 template <int KIND, bool COUNT, bool SHARE, int WAVES>
-__global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num_sgpr(80))) k_trace(TraceArgs a) {
+__global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8))) k_trace(TraceArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     float4* const s_nodes = reinterpret_cast<float4*>(s_raw);
     const uint32_t lane = threadIdx.x & 63u;
@@ -330,7 +385,8 @@ __global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num
     uint32_t pool_next = 0, pool_end = 0;  // wave-uniform: rays reserved for this wave
     uint32_t ray = 0, best_i = kHitNone;
     int sp = 0;
-    F3 o = f3(0, 0, 0), d = f3(0, 0, 0), rcp = f3(0, 0, 0);
+    F3 o = f3(0, 0, 0), d = f3(0, 0, 0);
+    Reciprocal zx = {0, 0}, zy = {0, 0}, zz = {0, 0};  // of d.x, d.y, d.z
     float best_t = kInfinity;
     float prior_t = kInfinity;              // distance already recorded for this ray by an earlier family
     uint32_t item = kItemNone;              // node reference in hand (branch or leaf)
@@ -377,7 +433,7 @@ __global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num
                     if (base + chunk >= n) exhausted = true;
                 }
                 const uint32_t take = min(n_idle, pool_end - pool_next);
-                const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
+                const uint32_t rank = bits_below_lane(idle);
                 if (!active && rank < take) {
                     const uint32_t idx = pool_next + rank;
                     ray = idx;
@@ -393,14 +449,16 @@ __global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num
                     // for the ray's loads (other waves of the SIMD cover that): a block deferred
                     // to the ray's first branch step measured 1.3 % slower, as every extra
                     // conditional region in this loop costs register moves where its values merge.
-                    // regime in which div_by2 equals `/` (see refine_rcp)
+                    // regime in which div_by2 equals `/` (see reciprocal_of)
                     const int d_ok = int(magnitude_in(d.x, 0x1p-30f, 2.0f)) & int(magnitude_in(d.y, 0x1p-30f, 2.0f)) &
                                      int(magnitude_in(d.z, 0x1p-30f, 2.0f));
                     const int o_ok = (int(o.x == 0.0f) | int(magnitude_in(o.x, 0x1p-60f, 0x1p59f))) &
                                      (int(o.y == 0.0f) | int(magnitude_in(o.y, 0x1p-60f, 0x1p59f))) &
                                      (int(o.z == 0.0f) | int(magnitude_in(o.z, 0x1p-60f, 0x1p59f)));
                     fast = (int(a.bounds_fast != 0) & d_ok & o_ok) != 0;
-                    rcp = f3(refine_rcp(d.x), refine_rcp(d.y), refine_rcp(d.z));
+                    zx = reciprocal_of(d.x);
+                    zy = reciprocal_of(d.y);
+                    zz = reciprocal_of(d.z);
                 }
                 pool_next += take;
             }
@@ -454,9 +512,9 @@ __global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num
                 bool h0, h1;
                 if (fast) {
                     const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
-                    const v2f t1x = div_by2(v2f{qx.x, qx.y} - ox, d.x, rcp.x), t2x = div_by2(v2f{qx.z, qx.w} - ox, d.x, rcp.x);
-                    const v2f t1y = div_by2(v2f{qy.x, qy.y} - oy, d.y, rcp.y), t2y = div_by2(v2f{qy.z, qy.w} - oy, d.y, rcp.y);
-                    const v2f t1z = div_by2(v2f{qz.x, qz.y} - oz, d.z, rcp.z), t2z = div_by2(v2f{qz.z, qz.w} - oz, d.z, rcp.z);
+                    const v2f t1x = div_by2(v2f{qx.x, qx.y} - ox, d.x, zx), t2x = div_by2(v2f{qx.z, qx.w} - ox, d.x, zx);
+                    const v2f t1y = div_by2(v2f{qy.x, qy.y} - oy, d.y, zy), t2y = div_by2(v2f{qy.z, qy.w} - oy, d.y, zy);
+                    const v2f t1z = div_by2(v2f{qz.x, qz.y} - oz, d.z, zz), t2z = div_by2(v2f{qz.z, qz.w} - oz, d.z, zz);
                     d0 = fmaxf(fmaxf(fminf(t1x.x, t2x.x), fminf(t1y.x, t2y.x)), fminf(t1z.x, t2z.x));
                     d1 = fmaxf(fmaxf(fminf(t1x.y, t2x.y), fminf(t1y.y, t2y.y)), fminf(t1z.y, t2z.y));
                     const float f0 = fminf(fminf(fmaxf(t1x.x, t2x.x), fmaxf(t1y.x, t2y.x)), fmaxf(t1z.x, t2z.x));
@@ -531,18 +589,16 @@ __global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num
                     __builtin_amdgcn_wave_barrier();
                     const uint32_t mark = __hip_atomic_load(&s_mark[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     const uint32_t owner = min(wave_scan_max(mark) - 1u, 63u);
-                    const uint32_t tri = __shfl(base, owner) + j;
-                    const F3 oo = f3(__shfl(o.x, owner), __shfl(o.y, owner), __shfl(o.z, owner));
-                    const F3 dd = f3(__shfl(d.x, owner), __shfl(d.y, owner), __shfl(d.z, owner));
+                    const uint32_t tri = from_lane(base, owner) + j;
+                    const F3 oo = f3(from_lane(o.x, owner), from_lane(o.y, owner), from_lane(o.z, owner));
+                    const F3 dd = f3(from_lane(d.x, owner), from_lane(d.y, owner), from_lane(d.z, owner));
                     if (COUNT) {
                         ++w_shape_runs;
                         w_shape_lanes += min(64u, N - cb);
                     }
                     if (j < N && tri < a.fam.n_shapes) {  // the second test only keeps a logic error from reading outside the table
-                        const float4* tp = reinterpret_cast<const float4*>(static_cast<const DTriangle*>(a.fam.shapes) + tri);
-                        const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
                         float t;
-                        if (triangle_hit(f3(v0.x, v0.y, v0.z), f3(v0.w, v1.x, v1.y), f3(v1.z, v1.w, v2.x), oo, dd, t))
+                        if (triangle_hit(static_cast<const DTriangle*>(a.fam.shapes) + tri, oo, dd, t))
                             atomicMin(&s_res[owner], (static_cast<unsigned long long>(__float_as_uint(t)) << 32) | tri);
                     }
                 }
@@ -574,9 +630,7 @@ __global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num
                 } else if (KIND == 1) {
                     hit = plane_hit(static_cast<const DPlane*>(a.fam.shapes)[i], o, d, t);
                 } else {
-                    const float4* tp = reinterpret_cast<const float4*>(static_cast<const DTriangle*>(a.fam.shapes) + i);
-                    const float4 v0 = tp[0], v1 = tp[1], v2 = tp[2];
-                    hit = triangle_hit(f3(v0.x, v0.y, v0.z), f3(v0.w, v1.x, v1.y), f3(v1.z, v1.w, v2.x), o, d, t);
+                    hit = triangle_hit(static_cast<const DTriangle*>(a.fam.shapes) + i, o, d, t);
                 }
                 if (hit && t < best_t) {
                     best_t = t;
@@ -910,7 +964,7 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
         }
         __syncthreads();
         if (alive) {
-            uint32_t dst = s_block_base + __popcll(live & ((1ull << lane) - 1ull));
+            uint32_t dst = s_block_base + bits_below_lane(live);
             for (uint32_t k = 0; k < wave; ++k) dst += s_wave_live[k];
             stream_store(&a.next.origin[dst], make_float4(no.x, no.y, no.z, 0.0f));
             stream_store(&a.next.direction[dst], make_float4(nd.x, nd.y, nd.z, 0.0f));
@@ -986,9 +1040,11 @@ __global__ void k_expand_texels(const uint8_t* rgb8, uint32_t* out, unsigned lon
 
 // Self-test of the shared-reciprocal division: compares div_by2 with `/` bit for
 // bit on pseudo-random operands drawn over the whole regime the traversal kernel
-// admits (|b| in [2^-30, 2), a == 0 or |a| in [2^-84, 2^60), either sign), plus
-// operands at the edges of that regime.  Counts quotients that differ (other
-// than in the sign of a zero).
+// admits (|b| in [2^-30, 2), a == 0 or |a| in [2^-84, 2^60), either sign), on
+// operands at the edges of that regime, on divisors whose significand is all
+// ones, and on dividends built so that the quotient lies next to the midpoint of
+// two neighbouring values (where a less careful sequence rounds the wrong way).
+// Counts quotients that differ (other than in the sign of a zero).
 __global__ void k_selftest_division(unsigned long long seed, uint32_t per_thread, unsigned long long* mismatches) {
     unsigned long long s = seed + (static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull;
     auto next = [&]() {
@@ -1005,17 +1061,40 @@ __global__ void k_selftest_division(unsigned long long seed, uint32_t per_thread
         // a: exponent 43..186 (2^-84 .. 2^59), random mantissa and sign; sometimes 0
         const uint32_t ae = 43u + static_cast<uint32_t>(r1 % 144u);
         float a0 = __uint_as_float((static_cast<uint32_t>(r1 >> 63) << 31) | (ae << 23) | (static_cast<uint32_t>(r1 >> 8) & 0x7FFFFFu));
-        float a1 = __uint_as_float(__float_as_uint(a0) ^ 0x00400001u);
         if ((i & 1023u) == 0u) a0 = 0.0f;
-        if ((i & 1023u) == 1u) { a0 = 0x1p-84f; a1 = -0x1.fffffep59f; }
         if ((i & 1023u) == 2u) { b = (i & 1024u) ? 0x1p-30f : -0x1.fffffep0f; }
-        if ((i & 1023u) == 3u) { b = __uint_as_float((__float_as_uint(b) & 0xFF800000u) | 0x7FFFFFu); }  // significand all ones
-        const float r = refine_rcp(b);
-        const v2f q = div_by2(v2f{a0, a1}, b, r);
+        if ((i & 7u) == 3u) { b = __uint_as_float((__float_as_uint(b) & 0xFF800000u) | 0x7FFFFFu); }  // significand all ones
+        // a1: b times a value half-way between two neighbours (25 significant bits, the
+        // last one set), rounded, then moved by -1..+2 units in the last place
+        float a1;
+        {
+            const uint32_t me = 70u + static_cast<uint32_t>((r1 >> 40) % 90u);  // quotient 2^-57 .. 2^32
+            const double mid = static_cast<double>(__uint_as_float((me << 23) | (static_cast<uint32_t>(r0 >> 33) & 0x7FFFFFu))) *
+                               (1.0 + 0x1p-24 / (1.0 + static_cast<double>(static_cast<uint32_t>(r0 >> 33) & 0x7FFFFFu) * 0x1p-23));
+            a1 = static_cast<float>(mid * static_cast<double>(b));
+            a1 = __uint_as_float(__float_as_uint(a1) + static_cast<uint32_t>(r1 >> 20 & 3u) - 1u);
+            if (!(fabsf(a1) >= 0x1p-84f && fabsf(a1) < 0x1p60f)) a1 = a0;
+        }
+        if ((i & 1023u) == 1u) { a0 = 0x1p-84f; a1 = -0x1.fffffep59f; }
+        const v2f q = div_by2(v2f{a0, a1}, b, reciprocal_of(b));
         const float w0 = a0 / b, w1 = a1 / b;
         const bool ok0 = __float_as_uint(q.x) == __float_as_uint(w0) || (q.x == 0.0f && w0 == 0.0f);
         const bool ok1 = __float_as_uint(q.y) == __float_as_uint(w1) || (q.y == 0.0f && w1 == 0.0f);
         bad += (ok0 ? 0u : 1u) + (ok1 ? 0u : 1u);
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+// Self-test of rcp_midrange: every binary32 value of either sign with magnitude
+// in [2^-20, 2^60) against `1.0f / b`, bit for bit.  Counts the differences.
+__global__ void k_selftest_reciprocal(unsigned long long* mismatches) {
+    const uint32_t lo = __float_as_uint(kRcpLo), hi = __float_as_uint(kRcpHi);
+    const uint32_t stride = gridDim.x * blockDim.x;
+    unsigned long long bad = 0;
+    for (uint32_t u = lo + blockIdx.x * blockDim.x + threadIdx.x; u < hi; u += stride) {
+        const float b = __uint_as_float(u);
+        bad += __float_as_uint(rcp_midrange(b)) != __float_as_uint(1.0f / b);
+        bad += __float_as_uint(rcp_midrange(-b)) != __float_as_uint(1.0f / -b);
     }
     if (bad) atomicAdd(mismatches, bad);
 }

@@ -48,9 +48,13 @@ struct alignas(16) DNode {
 static_assert(sizeof(DNode) == 64, "branch record must be one 64-byte line");
 
 struct alignas(16) DTriangle {
+    // per axis: (e2, e1) side by side — the two cross products of the
+    // intersection test, d x e2 and (o - a) x e1, run as the two halves of the
+    // packed (two-wide) arithmetic, so each loaded register pair is one operand
+    float ex[2];
+    float ey[2];
+    float ez[2];
     float a[3];
-    float e1[3];
-    float e2[3];
     float pad[3];
 };
 static_assert(sizeof(DTriangle) == 48, "triangle record is three 16-byte loads");

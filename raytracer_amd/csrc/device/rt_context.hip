@@ -961,8 +961,9 @@ int rt_upload_scene(RtContext* ctx, const RtSceneDesc* s) {
         for (uint32_t i = 0; i < s->n_triangles; ++i) {
             const RtTriangle& t = s->triangles[i];
             std::memcpy(tr[i].a, t.a, 12);
-            std::memcpy(tr[i].e1, t.e1, 12);
-            std::memcpy(tr[i].e2, t.e2, 12);
+            tr[i].ex[0] = t.e2[0]; tr[i].ex[1] = t.e1[0];
+            tr[i].ey[0] = t.e2[1]; tr[i].ey[1] = t.e1[1];
+            tr[i].ez[0] = t.e2[2]; tr[i].ez[1] = t.e1[2];
             tr[i].pad[0] = tr[i].pad[1] = tr[i].pad[2] = 0.0f;
             DTriSurface& d = ts[i];
             std::memset(&d, 0, sizeof d);
@@ -1189,12 +1190,16 @@ int rt_trace_rays(RtContext* ctx, const float* origins, const float* directions,
 
 int rt_self_test(RtContext* ctx, uint32_t which, uint64_t n_cases, uint64_t* failures) {
     if (!ctx || !failures) return RT_ERR_INVALID;
-    if (which != RT_SELF_TEST_DIVISION) return fail(ctx, RT_ERR_INVALID, "unknown self test");
+    if (which != RT_SELF_TEST_DIVISION && which != RT_SELF_TEST_RECIPROCAL) return fail(ctx, RT_ERR_INVALID, "unknown self test");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long), ctx->stream));
     const uint32_t threads = 256u * 1024u;
-    const uint32_t per_thread = static_cast<uint32_t>(std::min<uint64_t>((n_cases / 2 + threads - 1) / threads, 1u << 20));
-    hipLaunchKernelGGL(k_selftest_division, dim3(threads / 256), dim3(256), 0, ctx->stream, 0x1234567ull, per_thread, ctx->d_stats);
+    if (which == RT_SELF_TEST_DIVISION) {
+        const uint32_t per_thread = static_cast<uint32_t>(std::min<uint64_t>((n_cases / 2 + threads - 1) / threads, 1u << 20));
+        hipLaunchKernelGGL(k_selftest_division, dim3(threads / 256), dim3(256), 0, ctx->stream, 0x1234567ull, per_thread, ctx->d_stats);
+    } else {
+        hipLaunchKernelGGL(k_selftest_reciprocal, dim3(threads / 256), dim3(256), 0, ctx->stream, ctx->d_stats);
+    }
     HIP_TRY(ctx, hipGetLastError());
     unsigned long long bad = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&bad, ctx->d_stats, sizeof bad, hipMemcpyDeviceToHost, ctx->stream));

@@ -153,6 +153,13 @@ class Renderer:
         self._check(self._lib.rt_self_test(self._ctx, 1, n_cases, C.byref(bad)))
         return int(bad.value)
 
+    def self_test_reciprocal(self) -> int:
+        """Number of binary32 values in the triangle test's reciprocal range (all are
+        tried) whose reciprocal differs from `1.0f / x`; 0 on a correct build."""
+        bad = F.u64(0)
+        self._check(self._lib.rt_self_test(self._ctx, 2, 0, C.byref(bad)))
+        return int(bad.value)
+
     # ------------------------------------------------------------------- stats
     def stats(self) -> dict:
         s = F.RtStats()

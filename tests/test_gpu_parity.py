@@ -282,6 +282,11 @@ def test_shared_reciprocal_division_is_ieee_division(renderer):
     assert renderer.self_test_division(1 << 29) == 0
 
 
+def test_triangle_reciprocal_is_ieee_division(renderer):
+    # exhaustive: all 2 x 80 x 2^23 values of the range
+    assert renderer.self_test_reciprocal() == 0
+
+
 def test_extreme_coordinates_take_the_plain_division_path(renderer):
     # coordinates outside the regime of the shared-reciprocal division (tiny, huge,
     # and directions with tiny or zero components) must still match exactly
