@@ -337,7 +337,7 @@ __host__ __device__ inline size_t trace_lds_per_wave(uint32_t lds_slots) {
 // Eight waves per SIMD leave each wave 96 scalar registers, of which the
 // system's trap handler keeps 16: the kernel is held to the 80 that remain.
 template <int KIND, bool COUNT, bool SHARE, int WAVES>
-__global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8))) k_trace(TraceArgs a) {
+__global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(COUNT ? 4 : 8))) k_trace(TraceArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     float4* const s_nodes = reinterpret_cast<float4*>(s_raw);
     const uint32_t lane = threadIdx.x & 63u;
