@@ -291,7 +291,8 @@ def test_extreme_coordinates_take_the_plain_division_path(renderer):
     # coordinates outside the regime of the shared-reciprocal division (tiny, huge,
     # and directions with tiny or zero components) must still match exactly
     rng = np.random.default_rng(9)
-    for scale in (1e-25, 0.05, 3e4, 1e22):
+    # (3e10: determinants above 2^60, where the triangle test takes the general division as well)
+    for scale in (1e-25, 0.05, 3e4, 3e10, 1e22):
         v, f, _ = __import__("raytracer_amd").assets.grid_patch((-4 * scale, -4 * scale, 0), (8 * scale, 0, 0),
                                                                    (0, 8 * scale, 0), 8, 8)
         s = scenes.Scene.from_shapes(scenes.camera_params(w=16, h=16), triangles=scenes._triangles(v[f]),
@@ -307,7 +308,7 @@ def test_extreme_coordinates_take_the_plain_division_path(renderer):
         gpu, cpu = renderer.trace_rays(o, d), O.trace_rays(s, o, d)
         assert_hits_equal(gpu, cpu)
         # at the extreme scales nothing can be hit (|det| < 2e-6, or overflow), identically on both sides
-        assert (gpu["kind"] == F.RT_SHAPE_TRIANGLE).any() == (1e-3 < scale < 1e6)
+        assert (gpu["kind"] == F.RT_SHAPE_TRIANGLE).any() == (1e-3 < scale < 1e12)
 
 
 def test_errors_are_reported_not_fatal(renderer):
