@@ -250,6 +250,15 @@ __device__ inline float4 stream_load(const float4* p) {
     const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
     return make_float4(v.x, v.y, v.z, v.w);
 }
+typedef float nt_f3 __attribute__((ext_vector_type(3)));
+typedef nt_f3 nt_f3_packed __attribute__((aligned(4)));  // 12 bytes in memory, dword-aligned: one global_load_dwordx3
+__device__ inline F3 stream_load(const P3* p) {
+    const nt_f3 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f3_packed*>(p));
+    return F3{v.x, v.y, v.z};
+}
+__device__ inline void stream_store(P3* p, F3 v) {
+    __builtin_nontemporal_store(nt_f3{v.x, v.y, v.z}, reinterpret_cast<nt_f3_packed*>(p));
+}
 __device__ inline uint2 stream_load(const uint2* p) {
     const nt_u2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u2*>(p));
     return make_uint2(v.x, v.y);
@@ -437,8 +446,8 @@ __global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num
                 if (!active && rank < take) {
                     const uint32_t idx = pool_next + rank;
                     ray = idx;
-                    o = f3(stream_load(&a.q.origin[idx]));  // read once: kept out of the way of the node data in the caches
-                    d = f3(stream_load(&a.q.direction[idx]));
+                    o = stream_load(&a.q.origin[idx]);  // read once: kept out of the way of the node data in the caches
+                    d = stream_load(&a.q.direction[idx]);
                     prior_t = stream_load(&a.q.hit_t[idx]);
                     best_t = kInfinity;
                     best_i = kHitNone;
@@ -735,9 +744,9 @@ __global__ void k_raygen(FrameArgs f, DScene sc, DQueue q, uint32_t first_path, 
     const F3 pixel = (f3(f.top_left) + a) + b;
     const F3 cam = f3(f.camera);
     const F3 dir = normalize(pixel - cam);
-    q.origin[local] = make_float4(cam.x, cam.y, cam.z, 0.0f);
-    q.direction[local] = make_float4(dir.x, dir.y, dir.z, 0.0f);
-    q.throughput[local] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    q.origin[local] = P3{cam.x, cam.y, cam.z};
+    q.direction[local] = P3{dir.x, dir.y, dir.z};
+    q.throughput[local] = P3{1.0f, 1.0f, 1.0f};
     q.rng[local] = make_uint2(static_cast<uint32_t>(s), static_cast<uint32_t>(s >> 32));
     q.slot[local] = path;
     float ht;
@@ -753,11 +762,11 @@ __global__ void k_load_rays(const float* origins, const float* directions, DScen
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) *n_rays_out = n;
     if (i >= n) return;
-    q.origin[i] = make_float4(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], 0.0f);
-    q.direction[i] = make_float4(directions[3 * i], directions[3 * i + 1], directions[3 * i + 2], 0.0f);
+    q.origin[i] = P3{origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]};
+    q.direction[i] = P3{directions[3 * i], directions[3 * i + 1], directions[3 * i + 2]};
     float ht;
     uint32_t hid;
-    seed_hit(sc, f3(q.origin[i]), f3(q.direction[i]), ht, hid, test_counters);
+    seed_hit(sc, f3(&q.origin[i].x), f3(&q.direction[i].x), ht, hid, test_counters);
     q.hit_t[i] = ht;
     q.hit_id[i] = hid;
 }
@@ -840,8 +849,8 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
         unsigned long long rng = 0;
         uint32_t slot = 0;
         if (i < n) {
-            const F3 o = f3(stream_load(&a.cur.origin[i])), d = f3(stream_load(&a.cur.direction[i]));
-            thr = f3(stream_load(&a.cur.throughput[i]));
+            const F3 o = stream_load(&a.cur.origin[i]), d = stream_load(&a.cur.direction[i]);
+            thr = stream_load(&a.cur.throughput[i]);
             slot = stream_load(&a.cur.slot[i]);
             const uint32_t id = stream_load(&a.cur.hit_id[i]);
             if (id == kHitNone) {
@@ -966,9 +975,9 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
         if (alive) {
             uint32_t dst = s_block_base + bits_below_lane(live);
             for (uint32_t k = 0; k < wave; ++k) dst += s_wave_live[k];
-            stream_store(&a.next.origin[dst], make_float4(no.x, no.y, no.z, 0.0f));
-            stream_store(&a.next.direction[dst], make_float4(nd.x, nd.y, nd.z, 0.0f));
-            stream_store(&a.next.throughput[dst], make_float4(thr.x, thr.y, thr.z, 0.0f));
+            stream_store(&a.next.origin[dst], no);
+            stream_store(&a.next.direction[dst], nd);
+            stream_store(&a.next.throughput[dst], thr);
             stream_store(&a.next.rng[dst], make_uint2(static_cast<uint32_t>(rng), static_cast<uint32_t>(rng >> 32)));
             stream_store(&a.next.slot[dst], slot);
             float ht;

@@ -130,11 +130,18 @@ struct DScene {
     uint32_t inline_count[2];
 };
 
+// Three packed floats: the vectors of a path record are stored without a
+// fourth lane (every bounce streams all of them in and out once).
+struct P3 {
+    float x, y, z;
+};
+static_assert(sizeof(P3) == 12, "path vectors are 12 bytes apart");
+
 // One bounce's worth of live paths.
 struct DQueue {
-    float4* origin;
-    float4* direction;
-    float4* throughput;
+    P3* origin;
+    P3* direction;
+    P3* throughput;
     uint2* rng;
     uint32_t* slot;
     float* hit_t;

@@ -278,9 +278,9 @@ int ensure_pinned(RtContext* ctx, size_t words) {
 }
 
 int alloc_queue(RtContext* ctx, DQueue& q, size_t n) {
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&q.origin), n * sizeof(float4)));
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&q.direction), n * sizeof(float4)));
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&q.throughput), n * sizeof(float4)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&q.origin), n * sizeof(P3)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&q.direction), n * sizeof(P3)));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&q.throughput), n * sizeof(P3)));
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&q.rng), n * sizeof(uint2)));
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&q.slot), n * sizeof(uint32_t)));
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&q.hit_t), n * sizeof(float)));
@@ -513,7 +513,7 @@ size_t choose_samples_in_flight(const RtContext* ctx, size_t n_pixels, uint32_t 
     size_t s = ctx->opt_samples_in_flight;
     if (s == 0) {
         // Long queues amortise the thin tail of late bounces and the ends of launches: 2^28 paths
-        // (128 samples of a 1080p frame, 41 GB of queues) render 2.7 % faster than 2^26, and the
+        // (128 samples of a 1080p frame, 35 GB of queues) render 2.7 % faster than 2^26, and the
         // memory is there (288 GB); the caller of this function backs off when it is not.
         const size_t target_paths = size_t{1} << 28;
         s = std::max<size_t>(1, target_paths / std::max<size_t>(n_pixels, 1));
