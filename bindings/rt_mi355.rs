@@ -56,6 +56,17 @@ unsafe extern "C" {
         ctx: *mut RtContext, params: *const RtRenderParams, rgb8: *mut u8,
         progress: Option<unsafe extern "C" fn(u32, *mut c_void)>, user: *mut c_void,
     ) -> c_int;
+    /// Optional: the per-pixel fold of src/lib.rs:274-279 carried on from `sums` (samples
+    /// `0..sample_begin`) over `sample_count` more samples; with `rt_resolve` a progressive render
+    /// that does not average stored bytes.  `sums`: 3 f32 per pixel, kept by the caller.
+    pub fn rt_render_sums_onto(
+        ctx: *mut RtContext, params: *const RtRenderParams, sample_begin: u32, sample_count: u32,
+        sums: *mut f32, sums_on_device: c_int,
+    ) -> c_int;
+    pub fn rt_resolve(
+        ctx: *mut RtContext, params: *const RtRenderParams, sums: *const f32, sums_on_device: c_int,
+        n_samples: u32, running_average: c_int, sample_iteration: u32, rgb8: *mut u8,
+    ) -> c_int;
     /// Optional: `BvhNode::new` (src/bvh.rs:48) for the triangle slice on the GPU.  Permutes
     /// `shapes` in place like the host builder; `*nodes` is malloc'd, release it with `rt_free`.
     pub fn rt_build_bvh_triangles(

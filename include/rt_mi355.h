@@ -266,6 +266,19 @@ int rt_render_sums(RtContext* ctx, const RtRenderParams* params,
                    uint32_t sample_begin, uint32_t sample_count, float* sums,
                    int sums_on_device);
 
+/* The same fold carried on from an earlier call: on entry `sums` holds the
+ * fold of samples [0, sample_begin) (ignored when sample_begin is 0), on return
+ * that of [0, sample_begin + sample_count) — bit for bit what one call over the
+ * whole range gives, since the fold of :274-279 is sequential in sample order.
+ * With rt_resolve on the running total this is a progressive render whose
+ * preview does not go through the 8-bit running average of :286-292 (which
+ * loses precision every pass and drifts dark) and whose final image equals
+ * the non-incremental render of the same sample count.  The reference has no
+ * such mode; the caller keeps `sums` (for instance in a file beside the image). */
+int rt_render_sums_onto(RtContext* ctx, const RtRenderParams* params,
+                        uint32_t sample_begin, uint32_t sample_count, float* sums,
+                        int sums_on_device);
+
 /* Mean, gamma and quantisation of :283-295: rgb8 = u8(sqrt(sums/n)*255), or
  * with `running_average` the blend with the bytes already in `rgb8` weighted
  * by `sample_iteration`.  `sums` as in rt_render_sums; `rgb8` is host memory. */

@@ -529,7 +529,9 @@ int render_batch_overlapped(RtContext* ctx, const FrameArgs& f, const DScene& sc
 
 // The bounce loop over samples [s_begin, s_begin + count) of the region into
 // the workspace's running sums (lib.rs:260-279 for every pixel).
-int render_sums_device(RtContext* ctx, const RtRenderParams* p, const Region& r, uint32_t s_begin, uint32_t count) {
+// `initial` (optional): the fold of the samples before s_begin, which the fold goes on from.
+int render_sums_device(RtContext* ctx, const RtRenderParams* p, const Region& r, uint32_t s_begin, uint32_t count,
+                       const float* initial = nullptr, int initial_on_device = 0) {
     if (count == 0) return fail(ctx, RT_ERR_INVALID, "sample_count must be at least 1");
     const uint32_t B = p->max_bounces;
     size_t S = choose_samples_in_flight(ctx, r.n_pixels, count);
@@ -543,6 +545,9 @@ int render_sums_device(RtContext* ctx, const RtRenderParams* p, const Region& r,
     const FrameArgs f = frame_args(p, r);
     const DScene sc = device_scene(ctx);
     const uint32_t n_pix = static_cast<uint32_t>(r.n_pixels);
+    if (initial)
+        HIP_TRY(ctx, hipMemcpyAsync(w.sums, initial, r.n_pixels * 3 * sizeof(float),
+                                    initial_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
     uint32_t* counts = w.counters;           // [0..B]
     uint32_t* cursors = w.counters + B + 1;  // [B][3]
     const size_t counter_words = B + 1 + 3 * static_cast<size_t>(B);
@@ -595,7 +600,7 @@ int render_sums_device(RtContext* ctx, const RtRenderParams* p, const Region& r,
             }
         }
         hipLaunchKernelGGL(k_fold, dim3((n_pix + 255) / 256), dim3(256), 0, ctx->stream, w.result, w.sums, n_pix, nb,
-                           b0 == 0 ? 1 : 0);
+                           b0 == 0 && !initial ? 1 : 0);
         HIP_TRY(ctx, hipGetLastError());
         if (overlapped) {
             ctx->stats.segments += overlapped_segments;
@@ -1073,6 +1078,24 @@ int rt_render_sums(RtContext* ctx, const RtRenderParams* p, uint32_t sample_begi
     if (!sums) return fail(ctx, RT_ERR_INVALID, "null output");
     Timer timer;
     rc = render_sums_device(ctx, p, r, sample_begin, sample_count);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(sums, ctx->ws.sums, r.n_pixels * 3 * sizeof(float),
+                                sums_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stats.render_ms += timer.ms();
+    return RT_OK;
+}
+
+int rt_render_sums_onto(RtContext* ctx, const RtRenderParams* p, uint32_t sample_begin, uint32_t sample_count, float* sums,
+                        int sums_on_device) {
+    int rc = require_scene(ctx);
+    if (rc) return rc;
+    Region r;
+    rc = check_params(ctx, p, r);
+    if (rc) return rc;
+    if (!sums) return fail(ctx, RT_ERR_INVALID, "null accumulator");
+    Timer timer;
+    rc = render_sums_device(ctx, p, r, sample_begin, sample_count, sample_begin ? sums : nullptr, sums_on_device);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(sums, ctx->ws.sums, r.n_pixels * 3 * sizeof(float),
                                 sums_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));

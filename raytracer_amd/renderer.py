@@ -115,6 +115,16 @@ class Renderer:
         self._check(self._lib.rt_render_sums(self._ctx, C.byref(params), sample_begin, sample_count,
                                              C.c_void_p(device_ptr), 1))
 
+    def render_sums_onto(self, params, sample_begin: int, sample_count: int, sums: np.ndarray) -> np.ndarray:
+        """Carries the fold in `sums` (samples [0, sample_begin) of every pixel) on over
+        sample_count more samples, in place; equals render_sums(params, 0, begin + count)."""
+        h, w = params.tile_shape()
+        if sums.dtype != np.float32 or sums.shape != (h, w, 3) or not sums.flags.c_contiguous or not sums.flags.writeable:
+            raise ValueError("sums must be a writable C-contiguous float32 array of shape (h, w, 3)")
+        self._check(self._lib.rt_render_sums_onto(self._ctx, C.byref(params), sample_begin, sample_count,
+                                                  sums.ctypes.data, 0))
+        return sums
+
     def resolve(self, params, sums, n_samples: int, running_average: bool = False, sample_iteration: int = 0,
                 rgb8: np.ndarray | None = None, sums_on_device: bool = False) -> np.ndarray:
         h, w = params.tile_shape()
