@@ -2,7 +2,7 @@
 // (/root/reference/src/main.rs:5-8): read the file `scene` from the working
 // directory, parse it, render into the memory-mapped `target/out.ppm`.
 //
-//   rt_render [scene-file [output.ppm [gpu-ordinal [tile-edge]]]]
+//   rt_render [scene-file [output.ppm [gpu-ordinal [tile-edge [accumulator-file]]]]]
 //
 // `obj/<name>.obj` paths in the scene file are resolved against the working
 // directory, as in the reference.  The output file is never truncated, so a
@@ -14,11 +14,24 @@
 // tile's worth of paths is ever resident on the GPU; the image itself lives in
 // the page cache, as in the reference (README.md:18).  tile-edge 0 (default)
 // picks one tile for frames up to 2^24 pixels and 4096 x 4096 tiles beyond.
+//
+// With an accumulator file the run is progressive at full precision instead of
+// averaging the stored bytes (lib.rs:286-292): the file keeps the per-pixel f32
+// fold of all samples so far (32-byte header: "RTACC1", width, height, samples,
+// pass-in-progress mark, generator seed; then height x width x 3 f32), every run
+// adds the scene's samples per pixel in passes of `incremental` (or all at once)
+// and rewrites the image from the total, so after n samples the image is the
+// non-incremental render of n samples.  `continue` in the scene file is ignored
+// in this mode: the file knows where it stands.
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <sstream>
 #include <string>
@@ -39,11 +52,62 @@ static RtNode* build_triangles_on_gpu(void* user, RtTriangle* shapes, uint32_t n
     return nodes;
 }
 
+// The accumulator file, mapped (layout in the header comment).
+struct Accumulator {
+    struct Header {
+        char magic[8];
+        uint32_t width, height, samples, in_progress;
+        uint64_t seed;
+    };
+    static_assert(sizeof(Header) == 32, "header layout");
+    void* map = nullptr;
+    size_t size = 0;
+    Header* header() { return static_cast<Header*>(map); }
+    float* sums() { return reinterpret_cast<float*>(static_cast<char*>(map) + sizeof(Header)); }
+    void sync() { ::msync(map, size, MS_SYNC); }
+
+    bool open(const std::string& path, uint32_t w, uint32_t h, uint64_t seed) {
+        size = sizeof(Header) + static_cast<size_t>(w) * h * 12;
+        const int fd = ::open(path.c_str(), O_RDWR | O_CREAT, 0644);
+        if (fd < 0) return false;
+        struct stat st;
+        Header on_disk{};
+        bool fresh = ::fstat(fd, &st) != 0 || static_cast<size_t>(st.st_size) != size ||
+                     ::pread(fd, &on_disk, sizeof on_disk, 0) != static_cast<ssize_t>(sizeof on_disk);
+        fresh = fresh || std::memcmp(on_disk.magic, "RTACC1\0\0", 8) != 0 || on_disk.width != w || on_disk.height != h ||
+                on_disk.seed != seed;
+        if (fresh && (::ftruncate(fd, 0) != 0 || ::ftruncate(fd, static_cast<off_t>(size)) != 0)) {  // missing, or of another image
+            ::close(fd);
+            return false;
+        }
+        map = ::mmap(nullptr, size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        ::close(fd);
+        if (map == MAP_FAILED) return false;
+        if (fresh) {
+            std::memcpy(header()->magic, "RTACC1\0\0", 8);
+            header()->width = w;
+            header()->height = h;
+            header()->samples = 0;
+            header()->in_progress = 0;
+            header()->seed = seed;
+        }
+        return true;
+    }
+    void close() {
+        if (map && map != MAP_FAILED) {
+            sync();
+            ::munmap(map, size);
+        }
+        map = nullptr;
+    }
+};
+
 int main(int argc, char** argv) {
     const std::string scene_path = argc > 1 ? argv[1] : "scene";
     const std::string out_path = argc > 2 ? argv[2] : "target/out.ppm";
     const int gpu = argc > 3 ? std::atoi(argv[3]) : 0;
     uint32_t tile_edge = argc > 4 ? static_cast<uint32_t>(std::strtoul(argv[4], nullptr, 10)) : 0;
+    const std::string acc_path = argc > 5 ? argv[5] : "";
 
     std::ifstream in(scene_path);
     if (!in) {
@@ -83,7 +147,59 @@ int main(int argc, char** argv) {
     rc = rt_upload_scene(ctx, &desc);
     const uint64_t n_pixels = static_cast<uint64_t>(params.width) * params.height;
     if (tile_edge == 0 && n_pixels > (1ull << 24)) tile_edge = 4096;
-    if (rc == RT_OK && (tile_edge == 0 || (tile_edge >= params.width && tile_edge >= params.height))) {
+    if (rc == RT_OK && !acc_path.empty()) {
+        Accumulator acc;
+        if (!acc.open(acc_path, params.width, params.height, params.rng_seed)) {
+            std::fprintf(stderr, "cannot open accumulator file %s\n", acc_path.c_str());
+            return 1;
+        }
+        if (acc.header()->in_progress) {
+            std::fprintf(stderr, "%s was cut off in the middle of a pass; delete it to start over\n", acc_path.c_str());
+            return 1;
+        }
+        const uint32_t chunk = params.incremental ? params.incremental : params.samples_per_pixel;
+        if (chunk == 0 || params.samples_per_pixel % chunk != 0) {
+            std::fprintf(stderr, "incremental must divide the samples per pixel\n");
+            return 1;
+        }
+        const uint32_t edge_x = tile_edge ? std::min(tile_edge, params.width) : params.width;
+        const uint32_t edge_y = tile_edge ? std::min(tile_edge, params.height) : params.height;
+        std::vector<float> sums(static_cast<size_t>(edge_x) * edge_y * 3);
+        std::vector<uint8_t> tile(static_cast<size_t>(edge_x) * edge_y * 3);
+        for (uint32_t pass = 0; pass < params.samples_per_pixel / chunk && rc == RT_OK; ++pass) {
+            const uint32_t done = acc.header()->samples;
+            acc.header()->in_progress = 1;
+            acc.sync();
+            RtRenderParams tp = params;
+            tp.samples_per_pixel = chunk;
+            tp.incremental = tp.has_continue = tp.continue_sampling = 0;
+            for (uint32_t y = 0; y < params.height && rc == RT_OK; y += edge_y)
+                for (uint32_t x = 0; x < params.width && rc == RT_OK; x += edge_x) {
+                    tp.tile_x = x;
+                    tp.tile_y = y;
+                    tp.tile_w = std::min(edge_x, params.width - x);
+                    tp.tile_h = std::min(edge_y, params.height - y);
+                    const size_t row = static_cast<size_t>(tp.tile_w) * 3;
+                    for (uint32_t j = 0; j < tp.tile_h; ++j)
+                        std::memcpy(&sums[j * row], acc.sums() + (static_cast<size_t>(y + j) * params.width + x) * 3, row * sizeof(float));
+                    rc = rt_render_sums_onto(ctx, &tp, done, chunk, sums.data(), 0);
+                    if (rc != RT_OK) break;
+                    for (uint32_t j = 0; j < tp.tile_h; ++j)
+                        std::memcpy(acc.sums() + (static_cast<size_t>(y + j) * params.width + x) * 3, &sums[j * row], row * sizeof(float));
+                    rc = rt_resolve(ctx, &tp, sums.data(), 0, done + chunk, 0, 0, tile.data());
+                    if (rc == RT_OK) rth_image_write_tile(image, x, y, tp.tile_w, tp.tile_h, tile.data());
+                }
+            if (rc == RT_OK) {
+                acc.sync();  // the sums before the count that vouches for them
+                acc.header()->samples = done + chunk;
+                acc.header()->in_progress = 0;
+                acc.sync();
+                rth_image_flush(image);
+                progress(done + chunk, nullptr);
+            }
+        }
+        acc.close();
+    } else if (rc == RT_OK && (tile_edge == 0 || (tile_edge >= params.width && tile_edge >= params.height))) {
         rc = rt_render(ctx, &params, rth_image_pixels(image), progress, nullptr);
     } else if (rc == RT_OK) {
         // lib.rs:206-211,233-235: passes outermost, so the file is a whole image after each

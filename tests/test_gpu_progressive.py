@@ -2,11 +2,14 @@
 rt_render_sums_onto): whatever the split into passes, tiles and restarts, the
 image equals the one-shot render of the same sample count — the oracle's."""
 import os
+import subprocess
 
 import numpy as np
 import pytest
 
 from oracle import binding as O
+from raytracer_amd import _ffi as F
+from raytracer_amd import assets
 from raytracer_amd.progressive import Accumulator, render_progressive
 from raytracer_amd.tiles import Image
 
@@ -75,3 +78,27 @@ def test_side_file_of_another_image_or_a_cut_off_pass(renderer, tmp_path):
         with pytest.raises(RuntimeError):
             render_progressive(renderer, img, p, 1, 1, side)
     assert os.path.getsize(side) == 32 + 16 * 8 * 12
+
+
+def test_command_line_renderer_with_an_accumulator_file(asset_root, tmp_path):
+    """rt_render <scene> <out> <gpu> <tile> <acc>: two runs of 4 samples in passes of 2, tiled,
+    leave the one-shot image of 8 samples and a side file the Python reader agrees with."""
+    exe = os.path.join(F.LIB_DIR, "rt_render")
+    scene_file = tmp_path / "scene"
+    scene_file.write_text(assets.room_scene_text("room", 80, 50, 4, 8, incremental=2))
+    out, side = str(tmp_path / "a.ppm"), str(tmp_path / "a.acc")
+    for _ in range(2):
+        subprocess.run([exe, str(scene_file), out, "0", "32", side], cwd=asset_root, check=True, env=dict(os.environ), timeout=120)
+    scene = scenes.room(asset_root, w=80, h=50, spp=8, bounces=8)
+    want, _ = O.render(scene, scene.params, threads=4)
+    got = open(out, "rb").read()
+    assert got[len(b"P6\n80 50 255\n"):] == want.tobytes()
+    acc = Accumulator(side, 80, 50, scene.params.rng_seed)
+    assert acc.samples == 8 and not acc.in_progress
+    whole = O.render_sums(scene, scene.params, 0, 8, threads=4)
+    assert np.array_equal(bits(acc.sums), bits(whole))
+    acc.mark(8, True)
+    acc.close()
+    cut = subprocess.run([exe, str(scene_file), out, "0", "32", side], cwd=asset_root, env=dict(os.environ), timeout=120,
+                         capture_output=True)
+    assert cut.returncode == 1 and b"cut off" in cut.stderr
