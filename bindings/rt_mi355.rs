@@ -63,6 +63,16 @@ unsafe extern "C" {
         ctx: *mut RtContext, params: *const RtRenderParams, sample_begin: u32, sample_count: u32,
         sums: *mut f32, sums_on_device: c_int,
     ) -> c_int;
+    /// The two halves of `rt_render_sums_onto`: trace now (as many samples as fit; `*traced`),
+    /// fold later, onto sums that another GPU has carried up to this GPU's first sample.
+    pub fn rt_trace_samples(
+        ctx: *mut RtContext, params: *const RtRenderParams, sample_begin: u32, sample_count: u32,
+        traced: *mut u32,
+    ) -> c_int;
+    pub fn rt_fold_samples(
+        ctx: *mut RtContext, params: *const RtRenderParams, carry_on: c_int, sums: *mut f32,
+        sums_on_device: c_int,
+    ) -> c_int;
     pub fn rt_resolve(
         ctx: *mut RtContext, params: *const RtRenderParams, sums: *const f32, sums_on_device: c_int,
         n_samples: u32, running_average: c_int, sample_iteration: u32, rgb8: *mut u8,

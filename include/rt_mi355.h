@@ -279,6 +279,22 @@ int rt_render_sums_onto(RtContext* ctx, const RtRenderParams* params,
                         uint32_t sample_begin, uint32_t sample_count, float* sums,
                         int sums_on_device);
 
+/* The two halves of rt_render_sums_onto as separate calls, for a multi-GPU
+ * driver that wants the single-GPU image bit for bit: every GPU traces its
+ * contiguous share of a pass's samples at the same time (rt_trace_samples: the
+ * per-sample radiance stays on the device), then the running sums travel from
+ * GPU to GPU in sample order and each folds its samples onto them
+ * (rt_fold_samples with carry_on = 1; the first GPU starts the fold with
+ * carry_on = 0).  The fold of :274-279 is then the same sequence of additions
+ * as on one GPU.  rt_trace_samples traces as many of the `sample_count` samples
+ * as fit in flight at once and reports the number in `*traced`; the caller
+ * folds them and calls again for the rest.  A later render or trace call on the
+ * context discards samples not folded yet. */
+int rt_trace_samples(RtContext* ctx, const RtRenderParams* params,
+                     uint32_t sample_begin, uint32_t sample_count, uint32_t* traced);
+int rt_fold_samples(RtContext* ctx, const RtRenderParams* params, int carry_on,
+                    float* sums, int sums_on_device);
+
 /* Mean, gamma and quantisation of :283-295: rgb8 = u8(sqrt(sums/n)*255), or
  * with `running_average` the blend with the bytes already in `rgb8` weighted
  * by `sample_iteration`.  `sums` as in rt_render_sums; `rgb8` is host memory. */

@@ -62,6 +62,10 @@ struct RtContext {
     uint32_t n_chains = 2;                // independent chains a large batch is split into (1 = none)
     std::string error;
 
+    // samples traced by rt_trace_samples and not folded yet: pixels of the region, samples (0 = none)
+    size_t pending_pixels = 0;
+    uint32_t pending_samples = 0;
+
     bool has_scene = false;
     Family fam[3];
     uint32_t* sphere_material = nullptr;
@@ -527,6 +531,80 @@ size_t choose_samples_in_flight(const RtContext* ctx, size_t n_pixels, uint32_t 
 int render_batch_overlapped(RtContext* ctx, const FrameArgs& f, const DScene& sc, uint32_t B, uint32_t n_paths,
                             uint32_t n_pix, unsigned long long first_sample, uint64_t* segments_out);
 
+// One batch of the bounce loop: samples [first_sample, first_sample + nb) of every pixel
+// of the region, each path's final radiance left in the workspace's result array
+// ([sample in batch][pixel]).  The workspace must hold nb * n_pixels paths.
+int trace_batch(RtContext* ctx, const FrameArgs& f, const DScene& sc, uint32_t B, uint32_t n_pix, unsigned long long first_sample,
+                uint32_t nb) {
+    Workspace& w = ctx->ws;
+    uint32_t* counts = w.counters;           // [0..B]
+    uint32_t* cursors = w.counters + B + 1;  // [B][3]
+    const size_t counter_words = B + 1 + 3 * static_cast<size_t>(B);
+    const int shade_grid = ctx->n_cus * static_cast<int>(ctx->tune_shade_groups);
+    const uint32_t n_paths = nb * n_pix;
+    int rc = RT_OK;
+    ctx->stats.paths += n_paths;
+    // large batches run as two overlapped half-batches (not while counting: the counting kernels are slow anyway)
+    const bool overlapped = ctx->n_chains > 1 && !ctx->opt_count && B > 0 && n_paths >= (1u << 21);
+    if (overlapped) {
+        uint64_t overlapped_segments = 0;
+        rc = render_batch_overlapped(ctx, f, sc, B, n_paths, n_pix, first_sample, &overlapped_segments);
+        if (rc) return rc;
+        ctx->stats.segments += overlapped_segments;
+        return harvest(ctx);
+    }
+    HIP_TRY(ctx, hipMemsetAsync(counts, 0, std::max<size_t>(counter_words, 1) * sizeof(uint32_t), ctx->stream));
+    if (B == 0) {
+        // lib.rs:313,374: no bounce, no colour -> black
+        HIP_TRY(ctx, hipMemsetAsync(w.result, 0, static_cast<size_t>(n_paths) * sizeof(float4), ctx->stream));
+    } else {
+        hipLaunchKernelGGL(k_raygen, dim3((n_paths + 255) / 256), dim3(256), 0, ctx->stream, f, sc, w.q[0], 0u, n_paths,
+                           n_pix, first_sample, 1, counts, inline_counters(ctx));
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    for (uint32_t b = 0; b < B; ++b) {
+        const DQueue& cur = w.q[b & 1];
+        const DQueue& next = w.q[(b + 1) & 1];
+        rc = launch_trace(ctx, cur, counts + b, cursors + 3 * static_cast<size_t>(b));
+        if (rc) return rc;
+        ShadeArgs sa{};
+        sa.scene = sc;
+        sa.cur = cur;
+        sa.next = next;
+        sa.n_cur = counts + b;
+        sa.n_next = counts + b + 1;
+        sa.result = w.result;
+        sa.hits = ctx->d_stats;
+        sa.test_counters = inline_counters(ctx);
+        sa.last_bounce = b + 1 == B;
+        hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(256), 0, ctx->stream, sa);
+        HIP_TRY(ctx, hipGetLastError());
+        // every few bounces look whether any path is still alive
+        if ((b & 3) == 3 && b + 1 < B) {
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned, counts + b + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->h_pinned[0] == 0) break;
+        }
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned, counts, (B + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint32_t b = 0; b < B; ++b) ctx->stats.segments += ctx->h_pinned[b];
+    return harvest(ctx);
+}
+
+// Workspace for up to `count` samples of the region at once (fewer when the
+// automatic size does not fit the memory); returns the number that fit in *in_flight.
+int workspace_for_samples(RtContext* ctx, const Region& r, uint32_t count, uint32_t B, size_t* in_flight) {
+    size_t S = choose_samples_in_flight(ctx, r.n_pixels, count);
+    int rc = ensure_workspace(ctx, S * r.n_pixels, r.n_pixels, B);
+    while (rc == RT_ERR_OOM && S > 1 && ctx->opt_samples_in_flight == 0) {  // automatic size: take what fits
+        S = (S + 1) / 2;  // (ensure_workspace releases the queues of the failed attempt first)
+        rc = ensure_workspace(ctx, S * r.n_pixels, r.n_pixels, B);
+    }
+    *in_flight = S;
+    return rc;
+}
+
 // The bounce loop over samples [s_begin, s_begin + count) of the region into
 // the workspace's running sums (lib.rs:260-279 for every pixel).
 // `initial` (optional): the fold of the samples before s_begin, which the fold goes on from.
@@ -534,13 +612,10 @@ int render_sums_device(RtContext* ctx, const RtRenderParams* p, const Region& r,
                        const float* initial = nullptr, int initial_on_device = 0) {
     if (count == 0) return fail(ctx, RT_ERR_INVALID, "sample_count must be at least 1");
     const uint32_t B = p->max_bounces;
-    size_t S = choose_samples_in_flight(ctx, r.n_pixels, count);
-    int rc = ensure_workspace(ctx, S * r.n_pixels, r.n_pixels, B);
-    while (rc == RT_ERR_OOM && S > 1 && ctx->opt_samples_in_flight == 0) {  // automatic size: take what fits
-        S = (S + 1) / 2;  // (ensure_workspace releases the queues of the failed attempt first)
-        rc = ensure_workspace(ctx, S * r.n_pixels, r.n_pixels, B);
-    }
+    size_t S = 0;
+    int rc = workspace_for_samples(ctx, r, count, B, &S);
     if (rc) return rc;
+    ctx->pending_samples = 0;  // the result array is about to be overwritten
     Workspace& w = ctx->ws;
     const FrameArgs f = frame_args(p, r);
     const DScene sc = device_scene(ctx);
@@ -548,69 +623,13 @@ int render_sums_device(RtContext* ctx, const RtRenderParams* p, const Region& r,
     if (initial)
         HIP_TRY(ctx, hipMemcpyAsync(w.sums, initial, r.n_pixels * 3 * sizeof(float),
                                     initial_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
-    uint32_t* counts = w.counters;           // [0..B]
-    uint32_t* cursors = w.counters + B + 1;  // [B][3]
-    const size_t counter_words = B + 1 + 3 * static_cast<size_t>(B);
-    const int shade_grid = ctx->n_cus * static_cast<int>(ctx->tune_shade_groups);
-
     for (uint32_t b0 = 0; b0 < count; b0 += static_cast<uint32_t>(S)) {
         const uint32_t nb = std::min<uint32_t>(static_cast<uint32_t>(S), count - b0);
-        const uint32_t n_paths = nb * n_pix;
-        ctx->stats.paths += n_paths;
-        // large batches run as two overlapped half-batches (not while counting: the counting kernels are slow anyway)
-        const bool overlapped = ctx->n_chains > 1 && !ctx->opt_count && B > 0 && n_paths >= (1u << 21);
-        uint64_t overlapped_segments = 0;
-        if (overlapped) {
-            rc = render_batch_overlapped(ctx, f, sc, B, n_paths, n_pix, static_cast<unsigned long long>(s_begin) + b0,
-                                         &overlapped_segments);
-            if (rc) return rc;
-        } else {
-            HIP_TRY(ctx, hipMemsetAsync(counts, 0, std::max<size_t>(counter_words, 1) * sizeof(uint32_t), ctx->stream));
-            if (B == 0) {
-                // lib.rs:313,374: no bounce, no colour -> black
-                HIP_TRY(ctx, hipMemsetAsync(w.result, 0, static_cast<size_t>(n_paths) * sizeof(float4), ctx->stream));
-            } else {
-                hipLaunchKernelGGL(k_raygen, dim3((n_paths + 255) / 256), dim3(256), 0, ctx->stream, f, sc, w.q[0], 0u, n_paths,
-                                   n_pix, static_cast<unsigned long long>(s_begin) + b0, 1, counts, inline_counters(ctx));
-                HIP_TRY(ctx, hipGetLastError());
-            }
-        }
-        for (uint32_t b = 0; b < B && !overlapped; ++b) {
-            const DQueue& cur = w.q[b & 1];
-            const DQueue& next = w.q[(b + 1) & 1];
-            rc = launch_trace(ctx, cur, counts + b, cursors + 3 * static_cast<size_t>(b));
-            if (rc) return rc;
-            ShadeArgs sa{};
-            sa.scene = sc;
-            sa.cur = cur;
-            sa.next = next;
-            sa.n_cur = counts + b;
-            sa.n_next = counts + b + 1;
-            sa.result = w.result;
-            sa.hits = ctx->d_stats;
-            sa.test_counters = inline_counters(ctx);
-            sa.last_bounce = b + 1 == B;
-            hipLaunchKernelGGL(k_shade, dim3(shade_grid), dim3(256), 0, ctx->stream, sa);
-            HIP_TRY(ctx, hipGetLastError());
-            // every few bounces look whether any path is still alive
-            if ((b & 3) == 3 && b + 1 < B) {
-                HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned, counts + b + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-                if (ctx->h_pinned[0] == 0) break;
-            }
-        }
+        rc = trace_batch(ctx, f, sc, B, n_pix, static_cast<unsigned long long>(s_begin) + b0, nb);
+        if (rc) return rc;
         hipLaunchKernelGGL(k_fold, dim3((n_pix + 255) / 256), dim3(256), 0, ctx->stream, w.result, w.sums, n_pix, nb,
                            b0 == 0 && !initial ? 1 : 0);
         HIP_TRY(ctx, hipGetLastError());
-        if (overlapped) {
-            ctx->stats.segments += overlapped_segments;
-        } else {
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_pinned, counts, (B + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            for (uint32_t b = 0; b < B; ++b) ctx->stats.segments += ctx->h_pinned[b];
-        }
-        rc = harvest(ctx);
-        if (rc) return rc;
     }
     return RT_OK;
 }
@@ -1100,6 +1119,53 @@ int rt_render_sums_onto(RtContext* ctx, const RtRenderParams* p, uint32_t sample
     HIP_TRY(ctx, hipMemcpyAsync(sums, ctx->ws.sums, r.n_pixels * 3 * sizeof(float),
                                 sums_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stats.render_ms += timer.ms();
+    return RT_OK;
+}
+
+int rt_trace_samples(RtContext* ctx, const RtRenderParams* p, uint32_t sample_begin, uint32_t sample_count, uint32_t* traced) {
+    int rc = require_scene(ctx);
+    if (rc) return rc;
+    Region r;
+    rc = check_params(ctx, p, r);
+    if (rc) return rc;
+    if (!traced || sample_count == 0) return fail(ctx, RT_ERR_INVALID, "bad arguments");
+    Timer timer;
+    size_t S = 0;
+    rc = workspace_for_samples(ctx, r, sample_count, p->max_bounces, &S);
+    if (rc) return rc;
+    ctx->pending_samples = 0;
+    const uint32_t nb = std::min<uint32_t>(static_cast<uint32_t>(S), sample_count);
+    rc = trace_batch(ctx, frame_args(p, r), device_scene(ctx), p->max_bounces, static_cast<uint32_t>(r.n_pixels), sample_begin, nb);
+    if (rc) return rc;
+    ctx->pending_pixels = r.n_pixels;
+    ctx->pending_samples = nb;
+    *traced = nb;
+    ctx->stats.render_ms += timer.ms();
+    return RT_OK;
+}
+
+int rt_fold_samples(RtContext* ctx, const RtRenderParams* p, int carry_on, float* sums, int sums_on_device) {
+    if (!ctx) return RT_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Region r;
+    int rc = check_params(ctx, p, r);
+    if (rc) return rc;
+    if (!sums) return fail(ctx, RT_ERR_INVALID, "null accumulator");
+    if (ctx->pending_samples == 0 || ctx->pending_pixels != r.n_pixels)
+        return fail(ctx, RT_ERR_STATE, "no traced samples of this region are waiting to be folded");
+    Timer timer;
+    Workspace& w = ctx->ws;
+    const hipMemcpyKind in = sums_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    const hipMemcpyKind out = sums_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (carry_on) HIP_TRY(ctx, hipMemcpyAsync(w.sums, sums, r.n_pixels * 3 * sizeof(float), in, ctx->stream));
+    const uint32_t n_pix = static_cast<uint32_t>(r.n_pixels);
+    hipLaunchKernelGGL(k_fold, dim3((n_pix + 255) / 256), dim3(256), 0, ctx->stream, w.result, w.sums, n_pix, ctx->pending_samples,
+                       carry_on ? 0 : 1);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(sums, w.sums, r.n_pixels * 3 * sizeof(float), out, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pending_samples = 0;
     ctx->stats.render_ms += timer.ms();
     return RT_OK;
 }

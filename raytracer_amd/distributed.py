@@ -11,6 +11,12 @@ counter (/root/reference/src/lib.rs:213-235).
 Every (sample, pixel) has its own generator sub-stream, so the set of samples
 rendered does not depend on G; only the order in which per-rank partial sums
 are added differs from the single-GPU left fold (last-bit float differences).
+
+`render_pass_exact` removes that difference: the ranks trace their shares at the
+same time, then the running sums go from rank to rank in sample order and every
+rank folds its samples onto them, which is the single-GPU sequence of additions.
+The price is a chain of world-1 point-to-point transfers of the sums per pass
+instead of one reduce.
 """
 from __future__ import annotations
 
@@ -50,6 +56,37 @@ def render_pass(backend: SumsBackend, sample_begin: int, sample_count: int, worl
     return sums
 
 
+def render_pass_exact(backend, sample_begin: int, sample_count: int, world: int, rank: int,
+                      send: Callable | None, recv: Callable | None, to_rank0: bool = True):
+    """One pass whose result does not depend on `world`, bit for bit.  Returns the tensor
+    of sums, complete on the last rank (world - 1) and, with `to_rank0`, on rank 0.
+    `send(tensor, dst)` / `recv(tensor, src)` are `dist.send` / `dist.recv`; None when
+    world == 1.  `backend`: trace(begin, count) -> samples traced, fold(carry_on) ->
+    tensor, zeros(), .buffer (the tensor all of them work on)."""
+    first, mine = sample_share(sample_begin, sample_count, world, rank)
+    # earlier ranks take the larger shares, so a rank with samples has predecessors with samples
+    has_predecessor = rank > 0
+    traced = backend.trace(first, mine) if mine > 0 else 0  # every rank at the same time
+    if rank > 0:
+        recv(backend.buffer, rank - 1)
+    done = 0
+    while done < mine:
+        if done:  # the share did not fit in flight at once: the rest, piece by piece
+            traced = backend.trace(first + done, mine - done)
+        backend.fold(carry_on=has_predecessor or done > 0)
+        done += traced
+    if rank == 0 and mine == 0:
+        backend.zeros()
+    if rank + 1 < world:
+        send(backend.buffer, rank + 1)
+    if to_rank0 and world > 1:
+        if rank == world - 1:
+            send(backend.buffer, 0)
+        elif rank == 0:
+            recv(backend.buffer, world - 1)
+    return backend.buffer
+
+
 class GpuSumsBackend:
     """SumsBackend over librt_mi355.so: the library writes straight into a
     torch CUDA tensor through its device pointer."""
@@ -68,3 +105,10 @@ class GpuSumsBackend:
 
     def zeros(self):
         return self.buffer.zero_()
+
+    def trace(self, sample_begin: int, sample_count: int) -> int:
+        return self.renderer.trace_samples(self.params, sample_begin, sample_count)
+
+    def fold(self, carry_on: bool):
+        self.renderer.fold_samples(self.params, carry_on, self.buffer.data_ptr(), sums_on_device=True)
+        return self.buffer

@@ -125,6 +125,26 @@ class Renderer:
                                                   sums.ctypes.data, 0))
         return sums
 
+    def trace_samples(self, params, sample_begin: int, sample_count: int) -> int:
+        """Traces as many of the samples as fit in flight (their radiance stays on the
+        device until fold_samples) and returns how many that was."""
+        traced = F.u32(0)
+        self._check(self._lib.rt_trace_samples(self._ctx, C.byref(params), sample_begin, sample_count, C.byref(traced)))
+        return int(traced.value)
+
+    def fold_samples(self, params, carry_on: bool, sums, sums_on_device: bool = False):
+        """Folds the traced samples, in sample order, onto `sums` (carry_on) or into it
+        from nothing.  `sums`: float32 (h, w, 3) array, or a device pointer."""
+        if sums_on_device:
+            ptr = C.c_void_p(int(sums))
+        else:
+            h, w = params.tile_shape()
+            if sums.dtype != np.float32 or sums.shape != (h, w, 3) or not sums.flags.c_contiguous or not sums.flags.writeable:
+                raise ValueError("sums must be a writable C-contiguous float32 array of shape (h, w, 3)")
+            ptr = C.c_void_p(sums.ctypes.data)
+        self._check(self._lib.rt_fold_samples(self._ctx, C.byref(params), int(carry_on), ptr, int(sums_on_device)))
+        return sums
+
     def resolve(self, params, sums, n_samples: int, running_average: bool = False, sample_iteration: int = 0,
                 rgb8: np.ndarray | None = None, sums_on_device: bool = False) -> np.ndarray:
         h, w = params.tile_shape()

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from raytracer_amd.distributed import render_pass, sample_share
+from raytracer_amd.distributed import render_pass, render_pass_exact, sample_share
 
 
 def test_sample_shares_tile_the_range():
@@ -77,3 +77,61 @@ def test_sample_partitioned_render_matches_single_process(tmp_path, world, spp):
         acc = acc + p
     if world == 2:
         assert np.array_equal(got, acc)
+
+
+class OracleExactBackend:
+    """trace / fold / zeros / buffer over the CPU oracle: the per-sample radiance is kept
+    on the side (at most `capacity` samples at a time), the fold is the sequential
+    binary32 addition of /root/reference/src/lib.rs:274-279."""
+
+    def __init__(self, scene, capacity):
+        self.scene, self.capacity, self.pending = scene, capacity, []
+        h, w = scene.params.tile_shape()
+        self.buffer = torch.full((h * w * 3,), float("nan"), dtype=torch.float32)
+
+    def trace(self, begin, count):
+        from oracle import binding as O
+        n = min(count, self.capacity)
+        self.pending = [torch.from_numpy(O.render_sums(self.scene, self.scene.params, begin + k, 1).reshape(-1).copy())
+                        for k in range(n)]
+        return n
+
+    def fold(self, carry_on):
+        samples = list(self.pending)
+        acc = self.buffer.clone() if carry_on else samples.pop(0)
+        for x in samples:
+            acc = acc + x
+        self.buffer.copy_(acc)
+        self.pending = []
+        return self.buffer
+
+    def zeros(self):
+        return self.buffer.zero_()
+
+
+def _exact_worker(rank, world, port, spp, capacity, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import scenes
+    scene = scenes.materials(w=24, h=16, spp=spp)
+    sums = render_pass_exact(OracleExactBackend(scene, capacity), 0, spp, world, rank, dist.send, dist.recv)
+    if rank == 0:
+        np.save(out_path, sums.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world, spp, capacity", [(2, 7, 8), (3, 8, 2), (3, 2, 8), (1, 5, 2)])
+def test_exact_pass_is_the_single_process_fold_bit_for_bit(tmp_path, world, spp, capacity):
+    from oracle import binding as O
+    from tests import scenes
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "exact.npy")
+    mp.spawn(_exact_worker, args=(world, port, spp, capacity, out), nprocs=world, join=True)
+    got = np.load(out).reshape(16, 24, 3)
+    scene = scenes.materials(w=24, h=16, spp=spp)
+    want = O.render_sums(scene, scene.params, 0, spp)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
