@@ -113,6 +113,12 @@ class TileBackend(Protocol):
 
     def zeros(self, params): ...
 
+    def trace(self, params, sample_begin: int, sample_count: int) -> int:
+        """(exact groups only) Trace as many of the samples as fit; their radiance waits for fold."""
+
+    def fold(self, params, carry_on: bool):
+        """(exact groups only) Fold the traced samples onto the sums tensor (or start it); returns it."""
+
     def resolve(self, params, sums, n_samples: int, running: bool, k: int, old: np.ndarray | None) -> np.ndarray: ...
 
 
@@ -132,8 +138,15 @@ def pass_params(params, rect, chunk: int, running: bool, k: int):
 
 def render_tiled(backend: TileBackend, image: Image, params, tile_w: int, tile_h: int, world: int = 1, rank: int = 0,
                  group_size: int = 1, reduce_in_group: Callable | None = None, end_of_pass: Callable | None = None,
-                 progress: Callable | None = None) -> None:
+                 progress: Callable | None = None, exact_in_group: tuple[Callable, Callable] | None = None) -> None:
     """Render `params` (full image) into `image`.
+
+    exact_in_group = (send, recv), instead of reduce_in_group: `send(sums, member)` /
+    `recv(sums, member)` move a tile's sums to / from another member of this rank's group
+    (dist.send / dist.recv to the member's rank).  The members then trace their shares of
+    the tile's samples at the same time and fold them in sample order, the sums going from
+    member to member; the group's last member writes the tile, and its bytes are those of a
+    group of one (raytracer_amd.distributed.render_pass_exact, per tile).
 
     reduce_in_group(sums): sum over the ranks of this rank's group onto the
     group's first rank (dist.reduce on the group's process group); required when
@@ -144,8 +157,8 @@ def render_tiled(backend: TileBackend, image: Image, params, tile_w: int, tile_h
     """
     if world % group_size:
         raise ValueError("group size must divide the number of ranks")
-    if group_size > 1 and reduce_in_group is None:
-        raise ValueError("groups of several ranks need a reduce")
+    if group_size > 1 and reduce_in_group is None and exact_in_group is None:
+        raise ValueError("groups of several ranks need a reduce or the exact hand-over")
     n_groups, group, member = world // group_size, rank // group_size, rank % group_size
     chunk, n_passes, running, first_pass = passes(params)
     grid = tile_grid(int(params.width), int(params.height), tile_w, tile_h)
@@ -156,14 +169,32 @@ def render_tiled(backend: TileBackend, image: Image, params, tile_w: int, tile_h
     copier = ThreadPoolExecutor(max_workers=1)
     try:
         _render_passes(backend, image, params, grid, mine, copier, chunk, n_passes, running, first_pass, rank, group_size,
-                       member, reduce_in_group, end_of_pass, progress)
+                       member, reduce_in_group, end_of_pass, progress, exact_in_group)
     finally:
         copier.shutdown()
     image.flush()
 
 
+def _exact_tile_sums(backend, tp, first, n, group_size, member, send, recv):
+    """The tile's sums by the hand-over of render_pass_exact; complete on the last member."""
+    traced = backend.trace(tp, first, n) if n > 0 else 0  # every member at the same time
+    sums = backend.zeros(tp) if member == 0 and n == 0 else None
+    if member > 0:
+        sums = backend.sums(tp)
+        recv(sums, member - 1)
+    done = 0
+    while done < n:
+        if done:
+            traced = backend.trace(tp, first + done, n - done)
+        sums = backend.fold(tp, carry_on=member > 0 or done > 0)
+        done += traced
+    if member + 1 < group_size:
+        send(sums, member + 1)
+    return sums
+
+
 def _render_passes(backend, image, params, grid, mine, copier, chunk, n_passes, running, first_pass, rank, group_size,
-                   member, reduce_in_group, end_of_pass, progress) -> None:
+                   member, reduce_in_group, end_of_pass, progress, exact_in_group=None) -> None:
     for p in range(n_passes):
         k = p + first_pass
         if group_size == 1:
@@ -190,9 +221,12 @@ def _render_passes(backend, image, params, grid, mine, copier, chunk, n_passes, 
             else:
                 begin = 0
             first, n = sample_share(begin, chunk, group_size, member)
-            sums = backend.render_sums(tp, first, n) if n > 0 else backend.zeros(tp)
-            reduce_in_group(sums)
-            if member == 0:
+            if exact_in_group is not None:
+                sums = _exact_tile_sums(backend, tp, first, n, group_size, member, *exact_in_group)
+            else:
+                sums = backend.render_sums(tp, first, n) if n > 0 else backend.zeros(tp)
+                reduce_in_group(sums)
+            if member == (group_size - 1 if exact_in_group is not None else 0):
                 old = image.read_tile(x, y, w, h) if running else None
                 image.write_tile(x, y, backend.resolve(tp, sums, chunk, running, k, old))
         if end_of_pass is not None:
@@ -235,6 +269,17 @@ class GpuTileBackend:
 
     def zeros(self, params):
         return self._tensor(params).zero_()
+
+    def sums(self, params):
+        return self._tensor(params)
+
+    def trace(self, params, sample_begin, sample_count):
+        return self.renderer.trace_samples(params, sample_begin, sample_count)
+
+    def fold(self, params, carry_on):
+        t = self._tensor(params)
+        self.renderer.fold_samples(params, carry_on, t.data_ptr(), sums_on_device=True)
+        return t
 
     def resolve(self, params, sums, n_samples, running, k, old):
         h, w = params.tile_shape()

@@ -98,7 +98,7 @@ def test_command_line_renderer_tiles_large_frames(asset_root, tmp_path):
     assert a[len(b"P6\n80 50 255\n"):] == cpu.tobytes()
 
 
-def _hybrid_worker(rank, world, port, group_size, path, asset_root):
+def _hybrid_worker(rank, world, port, group_size, path, asset_root, exact=False):
     """One rank of the tile x sample hybrid, all ranks on GPU 0, reducing over gloo
     through host memory (a one-GPU box has no second GPU for RCCL to reach)."""
     import torch  # noqa: F401  (before the renderer: torch's HIP runtime must be the one loaded)
@@ -117,20 +117,28 @@ def _hybrid_worker(rank, world, port, group_size, path, asset_root):
         dist.reduce(host, dst=root, op=dist.ReduceOp.SUM, group=mine)
         t.copy_(host)
 
+    def send_to_member(t, member):
+        dist.send(t.cpu(), root + member)
+
+    def recv_from_member(t, member):
+        host = torch.empty(t.shape, dtype=t.dtype)
+        dist.recv(host, root + member)
+        t.copy_(host)
+
     scene = scenes.room(asset_root, w=72, h=48, spp=4, bounces=8)
     p = _with(scene, 4, incremental=2)
     with Renderer(0) as r:
         r.upload(scene)
         with Image(path, 72, 48) as img:
             render_tiled(GpuTileBackend(r, torch.device("cuda", 0)), img, p, 24, 24, world=world, rank=rank,
-                         group_size=group_size, reduce_in_group=reduce_in_group if group_size > 1 else None,
-                         end_of_pass=dist.barrier)
+                         group_size=group_size, reduce_in_group=reduce_in_group if group_size > 1 and not exact else None,
+                         exact_in_group=(send_to_member, recv_from_member) if exact else None, end_of_pass=dist.barrier)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world, group_size", [(2, 1), (2, 2), (4, 2)])
-def test_tiles_dealt_to_groups_of_ranks(asset_root, tmp_path, world, group_size):
+@pytest.mark.parametrize("world, group_size, exact", [(2, 1, False), (2, 2, False), (4, 2, False), (2, 2, True), (3, 3, True)])
+def test_tiles_dealt_to_groups_of_ranks(asset_root, tmp_path, world, group_size, exact):
     import socket
 
     import torch.multiprocessing as mp
@@ -139,13 +147,13 @@ def test_tiles_dealt_to_groups_of_ranks(asset_root, tmp_path, world, group_size)
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     path = str(tmp_path / "hybrid.ppm")
-    mp.spawn(_hybrid_worker, args=(world, port, group_size, path, asset_root), nprocs=world, join=True)
+    mp.spawn(_hybrid_worker, args=(world, port, group_size, path, asset_root, exact), nprocs=world, join=True)
     scene = scenes.room(asset_root, w=72, h=48, spp=4, bounces=8)
     want, _ = O.render(scene, _with(scene, 4, incremental=2), threads=4)
     with Image(path, 72, 48) as img:
         got = img.pixels().copy()
-    if group_size == 1:
-        assert np.array_equal(got, want)  # tiles only: no arithmetic differs
+    if group_size == 1 or exact:
+        assert np.array_equal(got, want)  # tiles only, or sums handed over in sample order: no arithmetic differs
     else:
         # the group's partial sums are added in another association: a truncated byte may move by one
         assert np.abs(got.astype(int) - want.astype(int)).max() <= 1

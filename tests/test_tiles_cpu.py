@@ -83,6 +83,28 @@ class OracleTileBackend:
         return O.resolve(params, sums.numpy().reshape(h, w, 3), n_samples, running, k,
                          None if old is None else np.ascontiguousarray(old))
 
+    # the exact hand-over inside a group: per-sample radiance kept until the fold
+    def sums(self, params):
+        h, w = params.tile_shape()
+        if getattr(self, "_sums", None) is None or self._sums.numel() != h * w * 3:
+            self._sums = torch.zeros(h * w * 3, dtype=torch.float32)
+        return self._sums
+
+    def trace(self, params, begin, count):
+        from oracle import binding as O
+        n = min(count, 1)  # one sample in flight: every share goes through the piece-by-piece path
+        self._pending = [torch.from_numpy(O.render_sums(self.scene, params, begin + j, 1).reshape(-1).copy()) for j in range(n)]
+        return n
+
+    def fold(self, params, carry_on):
+        t = self.sums(params)
+        samples = list(self._pending)
+        acc = t.clone() if carry_on else samples.pop(0)
+        for x in samples:
+            acc = acc + x
+        t.copy_(acc)
+        return t
+
 
 def _scene(spp, incremental=None, cont=None):
     from tests import scenes
@@ -123,7 +145,7 @@ def test_tiled_continue_resumes_from_the_file(tmp_path):
     assert passes(second.params) == (2, 1, True, 2)
 
 
-def _worker(rank, world, port, group_size, path):
+def _worker(rank, world, port, group_size, path, exact=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     scene = _scene(4, incremental=2)
@@ -133,26 +155,28 @@ def _worker(rank, world, port, group_size, path):
     root = (rank // group_size) * group_size
     with Image(path, 40, 28) as img:
         render_tiled(OracleTileBackend(scene), img, scene.params, 16, 16, world=world, rank=rank, group_size=group_size,
-                     reduce_in_group=(lambda t: dist.reduce(t, dst=root, op=dist.ReduceOp.SUM, group=mine)) if group_size > 1 else None,
+                     reduce_in_group=(lambda t: dist.reduce(t, dst=root, op=dist.ReduceOp.SUM, group=mine))
+                     if group_size > 1 and not exact else None,
+                     exact_in_group=((lambda t, m: dist.send(t, root + m)), (lambda t, m: dist.recv(t, root + m))) if exact else None,
                      end_of_pass=dist.barrier)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world, group_size", [(2, 1), (2, 2), (3, 1)])
-def test_tiles_across_processes(tmp_path, world, group_size):
+@pytest.mark.parametrize("world, group_size, exact", [(2, 1, False), (2, 2, False), (3, 1, False), (2, 2, True), (3, 3, True)])
+def test_tiles_across_processes(tmp_path, world, group_size, exact):
     from oracle import binding as O
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     path = str(tmp_path / "m.ppm")
-    mp.spawn(_worker, args=(world, port, group_size, path), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, group_size, path, exact), nprocs=world, join=True)
     with Image(path, 40, 28) as img:
         got = img.pixels().copy()
     scene = _scene(4, incremental=2)
     want, _ = O.render(scene, scene.params)
-    if group_size == 1:
-        assert np.array_equal(got, want)  # tile partition: no arithmetic differs
+    if group_size == 1 or exact:
+        assert np.array_equal(got, want)  # tile partition, or sums handed over in sample order: no arithmetic differs
     else:
         # sample partition inside the group: partial sums are added in another
         # association, which can move a truncated byte by one
