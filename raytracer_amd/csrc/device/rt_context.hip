@@ -62,8 +62,8 @@ struct RtContext {
     uint32_t n_chains = 2;                // independent chains a large batch is split into (1 = none)
     std::string error;
 
-    // samples traced by rt_trace_samples and not folded yet: pixels of the region, samples (0 = none)
-    size_t pending_pixels = 0;
+    // samples traced by rt_trace_samples and not folded yet: their region of the frame, how many (0 = none)
+    uint32_t pending_rect[6] = {0, 0, 0, 0, 0, 0};  // x0, y0, w, h, frame width, frame height
     uint32_t pending_samples = 0;
 
     bool has_scene = false;
@@ -1138,7 +1138,8 @@ int rt_trace_samples(RtContext* ctx, const RtRenderParams* p, uint32_t sample_be
     const uint32_t nb = std::min<uint32_t>(static_cast<uint32_t>(S), sample_count);
     rc = trace_batch(ctx, frame_args(p, r), device_scene(ctx), p->max_bounces, static_cast<uint32_t>(r.n_pixels), sample_begin, nb);
     if (rc) return rc;
-    ctx->pending_pixels = r.n_pixels;
+    const uint32_t rect[6] = {r.x0, r.y0, r.w, r.h, p->width, p->height};
+    std::copy(rect, rect + 6, ctx->pending_rect);
     ctx->pending_samples = nb;
     *traced = nb;
     ctx->stats.render_ms += timer.ms();
@@ -1152,7 +1153,8 @@ int rt_fold_samples(RtContext* ctx, const RtRenderParams* p, int carry_on, float
     int rc = check_params(ctx, p, r);
     if (rc) return rc;
     if (!sums) return fail(ctx, RT_ERR_INVALID, "null accumulator");
-    if (ctx->pending_samples == 0 || ctx->pending_pixels != r.n_pixels)
+    const uint32_t rect[6] = {r.x0, r.y0, r.w, r.h, p->width, p->height};
+    if (ctx->pending_samples == 0 || !std::equal(rect, rect + 6, ctx->pending_rect))
         return fail(ctx, RT_ERR_STATE, "no traced samples of this region are waiting to be folded");
     Timer timer;
     Workspace& w = ctx->ws;

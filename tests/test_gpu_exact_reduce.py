@@ -41,6 +41,16 @@ def test_shares_traced_apart_and_folded_in_order(renderer, in_flight):
                 renderer.fold_samples(s.params, rank > 0 or done > 0, acc)
                 done += n
         assert np.array_equal(bits(acc), bits(whole))
+        # samples traced for one region cannot be folded as another's
+        tile = s.params.copy()
+        tile.tile_x, tile.tile_y, tile.tile_w, tile.tile_h = 0, 0, 20, 24
+        other = s.params.copy()
+        other.tile_x, other.tile_y, other.tile_w, other.tile_h = 20, 0, 20, 24
+        renderer.trace_samples(tile, 0, 1)
+        with pytest.raises(RtError):
+            renderer.fold_samples(other, False, np.zeros((24, 20, 3), dtype=np.float32))
+        half = renderer.fold_samples(tile, False, np.zeros((24, 20, 3), dtype=np.float32))
+        assert np.array_equal(bits(half), bits(O.render_sums(s, tile, 0, 1)))
         # a render in between discards what was traced
         renderer.trace_samples(s.params, 0, 1)
         renderer.render_sums(s.params, 0, 1)
