@@ -350,6 +350,10 @@ def main() -> None:
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
                 "traffic_unit": "bytes per launch (memory-side counters, recorded profile)",
+                # algorithmic bytes are counted on the reference's data sizes, visit by visit; the tree and
+                # the triangles stay in LDS and L2, so the HBM traffic is a small part of them and `frac`
+                # can pass 1: the kernel is bound by instruction issue, not by this roofline
+                "note": "cache-resident working set: compare algorithmic_bytes_per_launch with traffic",
                 "algorithmic_bytes_per_launch": round(trace_bytes_per_ray * my_segments / my_launches),
                 "bytes_per_ray": round(trace_bytes_per_ray, 1),
                 "avg_launch_ms": round(my_trace_ms / my_launches, 4),
