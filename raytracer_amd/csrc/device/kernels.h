@@ -217,8 +217,10 @@ __device__ __forceinline__ bool magnitude_in(float v, float lo, float hi) {
     return m >= lo && m < hi;
 }
 
-// Persistent traversal kernel: one-wave workgroups; every lane owns one ray
-// and performs that ray's ordered traversal exactly as bvh.rs:227-298 does.
+// Persistent traversal kernel: workgroups of WAVES waves (1, 8 or 16; the waves
+// of a workgroup share only the LDS copy of the tree's top, see below k_trace);
+// every lane owns one ray and performs that ray's ordered traversal exactly as
+// bvh.rs:227-298 does.
 // Lanes that finish take new rays from a block of the queue the wave has
 // reserved (one atomic on the queue cursor per block of rays: a single shared
 // counter cannot serve one atomic per ray), so a wave stays busy until the
@@ -231,8 +233,9 @@ __device__ __forceinline__ bool magnitude_in(float v, float lo, float hi) {
 // pushed because its distance is below the closest hit, which has not changed),
 // so it is kept in hand instead of making the round trip through the stack.
 // Every iteration the wave votes: the branch step (one 64-byte record, two slab
-// tests) and the shape step (one shape per lane) each run only when enough
-// lanes wait for them.  A lane's own sequence of operations is never reordered,
+// tests) and the shape step (one shape per lane, or — triangles — all pending
+// (ray, triangle) pairs of the wave dealt out to its 64 lanes) each run only when
+// enough lanes wait for them.  A lane's own sequence of operations is never reordered,
 // only delayed, so results are those of the sequential algorithm.
 //
 // The stack's first `lds_slots` entries per lane live in LDS, laid out
