@@ -118,7 +118,10 @@ typedef struct RtTriangle {
     uint32_t material;
 } RtTriangle;
 
-/* Material, /root/reference/src/material.rs:11-15.  For a texture,
+/* Material, /root/reference/src/material.rs:11-15.  A textured material may be
+ * referenced by triangles only: rt_upload_scene refuses a sphere or plane with
+ * one (the reference's scene file cannot express it, config.rs:147-155, and
+ * their texture coordinates, shapes.rs:91-99,157-165, are not computed).  For a texture,
  * tex_offset is the byte offset of its first texel in RtSceneDesc.texels
  * (packed RGB8, row-major, top row first, as read from a P6 file). */
 typedef struct RtMaterial {

@@ -200,8 +200,21 @@ int build_family(RtContext* ctx, const char* name, const RtNode* nodes, uint32_t
         } else {
             // children are appended after their parent (bvh.rs:209-211); requiring
             // that also rules out cycles
-            if (nd.a <= i || nd.b <= i || nd.a >= n_nodes || nd.b >= n_nodes)
+            if (nd.a <= i || nd.b <= i || nd.a >= n_nodes || nd.b >= n_nodes || nd.a == nd.b)
                 return fail(ctx, RT_ERR_INVALID, std::string(name) + ": bad child index");
+        }
+    }
+    // a tree: no node has two parents (the depth computed below, which sizes the
+    // traversal stack, relies on it)
+    {
+        std::vector<uint8_t> has_parent(n_nodes, 0);
+        for (uint32_t i = 0; i < n_nodes; ++i) {
+            const RtNode& nd = nodes[i];
+            if (nd.b & RT_LEAF_BIT) continue;
+            for (uint32_t c : {nd.a, nd.b}) {
+                if (has_parent[c]) return fail(ctx, RT_ERR_INVALID, std::string(name) + ": node with two parents");
+                has_parent[c] = 1;
+            }
         }
     }
     // Branch records are numbered breadth-first from the root, so that the top of
@@ -295,6 +308,7 @@ int alloc_queue(RtContext* ctx, DQueue& q, size_t n) {
 int ensure_workspace(RtContext* ctx, size_t n_paths, size_t n_pixels, size_t n_bounces) {
     Workspace& w = ctx->ws;
     if (w.cap_paths < n_paths) {
+        ctx->pending_samples = 0;  // traced samples waiting in the result array go with it
         free_queue(w.q[0]);
         free_queue(w.q[1]);
         (void)hipFree(w.result);
@@ -914,6 +928,7 @@ int rt_upload_scene(RtContext* ctx, const RtSceneDesc* s) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     free_scene(ctx);
+    ctx->pending_samples = 0;  // samples traced against the previous scene are not folded into a new one's sums
 
     // ---- validation of everything a kernel indexes with
     if ((s->n_spheres && !s->spheres) || (s->n_planes && !s->planes) || (s->n_triangles && !s->triangles) ||
@@ -922,10 +937,18 @@ int rt_upload_scene(RtContext* ctx, const RtSceneDesc* s) {
         return fail(ctx, RT_ERR_INVALID, "null array with a non-zero count");
     if (s->n_spheres > kHitPrimMask || s->n_planes > kHitPrimMask || s->n_triangles > kHitPrimMask)
         return fail(ctx, RT_ERR_INVALID, "too many shapes");
-    for (uint32_t i = 0; i < s->n_spheres; ++i)
+    // Spheres and planes take solid colours only: the scene file cannot give them a texture
+    // (config.rs:147-155), so their texture coordinates (shapes.rs:91-99,157-165) are not computed.
+    for (uint32_t i = 0; i < s->n_spheres; ++i) {
         if (s->spheres[i].material >= s->n_materials) return fail(ctx, RT_ERR_INVALID, "sphere material index out of range");
-    for (uint32_t i = 0; i < s->n_planes; ++i)
+        if (s->materials[s->spheres[i].material].color_kind == RT_COLOR_TEXTURE)
+            return fail(ctx, RT_ERR_INVALID, "textured materials are supported on triangles only (sphere)");
+    }
+    for (uint32_t i = 0; i < s->n_planes; ++i) {
         if (s->planes[i].material >= s->n_materials) return fail(ctx, RT_ERR_INVALID, "plane material index out of range");
+        if (s->materials[s->planes[i].material].color_kind == RT_COLOR_TEXTURE)
+            return fail(ctx, RT_ERR_INVALID, "textured materials are supported on triangles only (plane)");
+    }
     for (uint32_t i = 0; i < s->n_triangles; ++i) {
         const RtTriangle& t = s->triangles[i];
         if (t.material >= s->n_materials) return fail(ctx, RT_ERR_INVALID, "triangle material index out of range");
@@ -1067,6 +1090,10 @@ int rt_upload_scene(RtContext* ctx, const RtSceneDesc* s) {
                                      (node_arrays[k][0].b & ~RT_LEAF_BIT) == shape_counts[k];
             ctx->inline_count[k] = single_leaf && shape_counts[k] <= kInlineMax ? shape_counts[k] : 0;
         }
+        // A seeded plane hit would be found before the sphere family's traversal has run, and an
+        // equal distance must go to the sphere (lib.rs:333 keeps the first family): planes are
+        // scanned at ray creation only when no sphere traversal comes after it.
+        if (shape_counts[0] != 0 && ctx->inline_count[0] == 0) ctx->inline_count[1] = 0;
     }
     HIP_TRY(ctx, hipDeviceSynchronize());  // uploads above went through the default stream
 
