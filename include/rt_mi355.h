@@ -317,6 +317,21 @@ int rt_trace_primary(RtContext* ctx, const RtRenderParams* params,
 int rt_trace_rays(RtContext* ctx, const float* origins, const float* directions,
                   uint64_t n_rays, RtHitRecord* out);
 
+/* rt_trace_rays for callers that cannot allocate device memory (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has
+ * no counterpart in the reference.  Same results as rt_trace_rays, bit for bit,
+ * but every intermediate (ray queue, hit records, traversal stack overflow)
+ * lives in a fixed 64 MiB array that is part of the library's code object — one
+ * copy per GPU, held until the process ends — so the call performs no
+ * hipMalloc / hipFree and no host allocation.  At most 524288 rays per call
+ * (RT_ERR_INVALID beyond that).  `origins`, `directions` and `out` are host
+ * pointers, or device pointers on this context's GPU when `on_device` is
+ * non-zero.  All contexts on one GPU share that GPU's array: calls that overlap
+ * in time on one GPU (from different contexts or threads) race; calls in
+ * sequence are independent of each other. */
+int rt_trace_rays_noalloc(RtContext* ctx, const float* origins, const float* directions,
+                          uint64_t n_rays, RtHitRecord* out, int on_device);
+
 /* `BvhNode::new` for the triangle family, /root/reference/src/bvh.rs:48-224, on
  * the GPU: the same contract as the host builder (rth_build_bvh_triangles in
  * rt_host.h) and the same result — `shapes` is permuted in place exactly as the

@@ -114,6 +114,7 @@ _DEVICE_SYMBOLS = {
                              u32, C.c_void_p]),
     "rt_trace_primary": (C.c_int, [C.c_void_p, C.POINTER(RtRenderParams), u32, C.c_int, C.c_void_p]),
     "rt_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u64, C.c_void_p]),
+    "rt_trace_rays_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, u64, C.c_void_p, C.c_int]),
     "rt_build_bvh_triangles": (C.c_int, [C.c_void_p, C.c_void_p, u32, C.POINTER(C.c_void_p), C.POINTER(u32)]),
     "rt_build_bvh_spheres": (C.c_int, [C.c_void_p, C.c_void_p, u32, C.POINTER(C.c_void_p), C.POINTER(u32)]),
     "rt_free": (None, [C.c_void_p]),

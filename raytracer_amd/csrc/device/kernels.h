@@ -774,6 +774,23 @@ __global__ void k_load_rays(const float* origins, const float* directions, DScen
     q.hit_id[i] = hid;
 }
 
+// Hit queue entries -> {distance, family, primitive} records (the layout of the
+// C ABI's RtHitRecord), on the device.
+struct HitOut {
+    float t;
+    uint32_t kind, prim;
+};
+__global__ void k_hit_records(const float* hit_t, const uint32_t* hit_id, HitOut* out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t id = hit_id[i];
+    HitOut h;
+    h.t = hit_t[i];
+    h.kind = id == kHitNone ? 3u : id >> kHitKindShift;
+    h.prim = id == kHitNone ? 0xFFFFFFFFu : id & kHitPrimMask;
+    out[i] = h;
+}
+
 // ------------------------------------------------------------------- shade
 
 // material.rs:192-239

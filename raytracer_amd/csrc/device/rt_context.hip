@@ -9,7 +9,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
-#include <map>
 #include <string>
 #include <vector>
 
@@ -49,6 +48,26 @@ struct Workspace {
 
 }  // namespace
 
+// ---- scratch of the entry point that allocates nothing (rt_trace_rays_noalloc)
+//
+// One array per GPU, part of the loaded code object, held until the process ends.
+// In host code the name `scratch` is only a handle for hipGetSymbolAddress: the
+// device address of this GPU's copy is looked up once per context (rt_create) and
+// kept in RtContext::scratch; kernels, memsets and copies are given that pointer.
+constexpr size_t kScratchBytes = size_t{64} << 20;
+constexpr uint64_t kNoAllocMaxRays = uint64_t{1} << 19;
+// layout: [0, 256) counters; then seven per-ray arrays of kNoAllocMaxRays entries (origin,
+// direction, hit distance, hit id, result records, and the two staging arrays for rays handed
+// over in host memory: 68 bytes per ray, 34 MiB); the rest (from 36 MiB) is the overflow area of
+// deep traversal stacks
+constexpr size_t kScratchQueue = 256;
+constexpr size_t kScratchSpill = size_t{36} << 20;
+constexpr size_t kScratchSpillEntries = (kScratchBytes - kScratchSpill) / sizeof(uint2);
+static_assert(kScratchQueue + kNoAllocMaxRays * 68 <= kScratchSpill, "per-ray arrays overlap the overflow area");
+static_assert(sizeof(RtHitRecord) == sizeof(HitOut) && offsetof(RtHitRecord, prim) == offsetof(HitOut, prim),
+              "k_hit_records writes RtHitRecord");
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
 struct RtContext {
     int device = 0;
     int n_cus = 0;
@@ -83,7 +102,20 @@ struct RtContext {
     uint32_t* h_pinned = nullptr;           // small pinned read-back area
     size_t h_pinned_words = 0;
 
-    std::map<std::pair<const void*, size_t>, int> trace_occupancy;  // (kernel, LDS bytes) -> workgroups per CU
+    // (kernel, LDS bytes) -> workgroups per CU; a small fixed table (oldest entry replaced), so
+    // that a launch never allocates host memory
+    struct Occupancy {
+        const void* fn = nullptr;
+        size_t lds = 0;
+        int per_cu = 0;
+    } trace_occupancy[32];
+    uint32_t trace_occupancy_next = 0;
+    // overrides for the entry point that allocates nothing: where deep traversal stacks overflow to
+    // (null = the workspace's area of the launching chain) and how many threads that area serves
+    uint2* launch_spill = nullptr;
+    uint32_t launch_max_threads = 0;
+    unsigned char* scratch = nullptr;  // this GPU's copy of the file-scope scratch array (see rt_trace_rays_noalloc)
+    uint32_t deepest_stack = 1;    // largest max_stack over the uploaded scene's three families
     uint32_t max_grid_threads = 0; // upper bound of the traversal grid's threads (sizes the spill area)
     uint32_t tune_lds_slots = 6, tune_phase_min = 24, tune_chunk_max = 256, tune_pair_min = 384;
     uint32_t tune_waves_per_cu = 0; // traversal waves resident per CU (0 = all the kernel's occupancy allows)
@@ -419,9 +451,10 @@ int launch_trace_variant(RtContext* ctx, TraceArgs a) {
     const int block = kTraceBlock * WAVES;
     a.cache_nodes = WAVES > 1 ? std::min(ctx->tune_cache_nodes, ctx->fam[KIND].n_branches) : 0u;
     const size_t lds = static_cast<size_t>(a.cache_nodes) * sizeof(DNode) + WAVES * trace_lds_per_wave(a.lds_slots);
-    const auto key = std::make_pair(fn, lds);
-    auto it = ctx->trace_occupancy.find(key);
-    if (it == ctx->trace_occupancy.end()) {
+    const RtContext::Occupancy* it = nullptr;
+    for (const RtContext::Occupancy& o : ctx->trace_occupancy)
+        if (o.fn == fn && o.lds == lds) it = &o;
+    if (!it) {
         if (lds > 64 * 1024)
             HIP_TRY(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
         int per_cu = 0;
@@ -431,14 +464,19 @@ int launch_trace_variant(RtContext* ctx, TraceArgs a) {
         if (std::getenv("RT_MI355_DEBUG_TALLIES"))
             std::fprintf(stderr, "[rt_mi355] traversal kind %d: %d waves per workgroup, %zu bytes of LDS, %d workgroups per CU\n",
                          KIND, WAVES, lds, per_cu);
-        it = ctx->trace_occupancy.emplace(key, per_cu).first;
+        RtContext::Occupancy& slot = ctx->trace_occupancy[ctx->trace_occupancy_next++ % 32u];
+        slot = RtContext::Occupancy{fn, lds, per_cu};
+        it = &slot;
     }
     // share of the CU's 32 wave slots: the caller's setting, or the overlapped render loop's
     uint32_t wave_cap = ctx->tune_waves_per_cu ? ctx->tune_waves_per_cu : (ctx->wave_cap_now ? ctx->wave_cap_now : 32u);
-    const uint32_t per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(static_cast<uint32_t>(it->second), wave_cap / WAVES));
-    const uint32_t grid = static_cast<uint32_t>(ctx->n_cus) * per_cu;
+    const uint32_t per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(static_cast<uint32_t>(it->per_cu), wave_cap / WAVES));
+    uint32_t grid = static_cast<uint32_t>(ctx->n_cus) * per_cu;
+    const uint32_t thread_limit = ctx->launch_max_threads ? ctx->launch_max_threads : ctx->max_grid_threads;
+    if (ctx->launch_max_threads) grid = std::min(grid, thread_limit / static_cast<uint32_t>(block));
+    if (grid == 0) return fail(ctx, RT_ERR_INVALID, "stack overflow area too small for one traversal workgroup");
     a.spill_stride = grid * static_cast<uint32_t>(block);
-    if (a.spill_stride > ctx->max_grid_threads) return fail(ctx, RT_ERR_INVALID, "traversal grid larger than the stack overflow area");
+    if (a.spill_stride > thread_limit) return fail(ctx, RT_ERR_INVALID, "traversal grid larger than the stack overflow area");
     hipLaunchKernelGGL((k_trace<KIND, COUNT, SHARE, WAVES>), dim3(grid), dim3(block), lds, ctx->launch_stream, a);
     return RT_OK;
 }
@@ -470,7 +508,7 @@ int launch_trace(RtContext* ctx, const DQueue& q, const uint32_t* n_rays, uint32
         a.q = q;
         a.n_rays = n_rays;
         a.cursor = cursors + kind;
-        a.spill = ctx->ws.spill + ctx->ws.spill_entries * ctx->launch_chain;
+        a.spill = ctx->launch_spill ? ctx->launch_spill : ctx->ws.spill + ctx->ws.spill_entries * ctx->launch_chain;
         a.lds_slots = ctx->tune_lds_slots;
         a.phase_min = ctx->tune_phase_min;
         a.chunk_max = ctx->tune_chunk_max;
@@ -842,6 +880,15 @@ int rt_create(int device_ordinal, RtContext** out) {
         delete ctx;
         return RT_ERR_HIP;
     }
+    // this GPU's copy of the scratch array (the device is current here)
+    void* scratch_ptr = nullptr;
+    if (hipGetSymbolAddress(&scratch_ptr, HIP_SYMBOL(scratch)) != hipSuccess || !scratch_ptr) {
+        (void)hipGetLastError();
+        rt_destroy(ctx);
+        return RT_ERR_HIP;
+    }
+    ctx->scratch = static_cast<unsigned char*>(scratch_ptr);
+    ctx->error.reserve(256);  // later messages of that length are stored without allocating
     ctx->d_inline_tests = ctx->d_stats + 7;
     ctx->launch_stream = ctx->stream;
     ctx->chain_stream[0] = ctx->stream;
@@ -985,6 +1032,7 @@ int rt_upload_scene(RtContext* ctx, const RtSceneDesc* s) {
         if (rc) { free_scene(ctx); return rc; }
         deepest = std::max(deepest, ctx->fam[k].max_stack);
     }
+    ctx->deepest_stack = deepest;
 
     // ---- shapes
     {
@@ -1304,6 +1352,82 @@ int rt_trace_rays(RtContext* ctx, const float* origins, const float* directions,
     rc = harvest(ctx);
     if (rc) return rc;
     return download_hits(ctx, w.q[0], n, out);
+}
+
+// Error paths of the entry point below: a literal copied into the context's message
+// buffer (capacity reserved at creation), no temporary strings.
+static int fail_literal(RtContext* ctx, int code, const char* msg) {
+    ctx->error.assign(msg);
+    return code;
+}
+#define HIP_TRY_LITERAL(ctx, expr)                                                        \
+    do {                                                                                  \
+        if ((expr) != hipSuccess) {                                                       \
+            (void)hipGetLastError();                                                      \
+            ctx->launch_spill = nullptr;                                                  \
+            ctx->launch_max_threads = 0;                                                  \
+            return fail_literal(ctx, RT_ERR_HIP, "HIP call failed: " #expr);              \
+        }                                                                                 \
+    } while (0)
+
+int rt_trace_rays_noalloc(RtContext* ctx, const float* origins, const float* directions, uint64_t n_rays, RtHitRecord* out,
+                          int on_device) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->has_scene) return fail_literal(ctx, RT_ERR_STATE, "no scene uploaded");
+    if (n_rays == 0) return RT_OK;
+    if (!origins || !directions || !out) return fail_literal(ctx, RT_ERR_INVALID, "null ray arrays");
+    if (n_rays > kNoAllocMaxRays)
+        return fail_literal(ctx, RT_ERR_INVALID, "rt_trace_rays_noalloc takes at most 524288 rays per call (fixed scratch array)");
+    static_assert(kNoAllocMaxRays == 524288, "the message above states the limit");
+    HIP_TRY_LITERAL(ctx, hipSetDevice(ctx->device));
+    const uint32_t n = static_cast<uint32_t>(n_rays);
+    // carve this GPU's scratch array (always through the looked-up device pointer)
+    unsigned char* const base = ctx->scratch;
+    uint32_t* const counters = reinterpret_cast<uint32_t*>(base);
+    unsigned char* at = base + kScratchQueue;
+    auto take = [&](size_t bytes_per_ray) {
+        unsigned char* p = at;
+        at += kNoAllocMaxRays * bytes_per_ray;
+        return p;
+    };
+    DQueue q{};
+    q.origin = reinterpret_cast<P3*>(take(sizeof(P3)));
+    q.direction = reinterpret_cast<P3*>(take(sizeof(P3)));
+    q.hit_t = reinterpret_cast<float*>(take(sizeof(float)));
+    q.hit_id = reinterpret_cast<uint32_t*>(take(sizeof(uint32_t)));
+    HitOut* const records = reinterpret_cast<HitOut*>(take(sizeof(HitOut)));
+    float* const stage_o = reinterpret_cast<float*>(take(3 * sizeof(float)));
+    float* const stage_d = reinterpret_cast<float*>(take(3 * sizeof(float)));
+    // the overflow area serves as many traversal threads as the scene's deepest stack leaves room for
+    const uint32_t spill_threads = static_cast<uint32_t>(std::min<size_t>(kScratchSpillEntries / ctx->deepest_stack, ctx->max_grid_threads));
+    // counters must start at zero; everything else is written before it is read
+    HIP_TRY_LITERAL(ctx, hipMemsetAsync(counters, 0, kScratchQueue, ctx->stream));
+    const float* d_o = origins;
+    const float* d_d = directions;
+    if (!on_device) {
+        HIP_TRY_LITERAL(ctx, hipMemcpyAsync(stage_o, origins, n_rays * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY_LITERAL(ctx, hipMemcpyAsync(stage_d, directions, n_rays * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        d_o = stage_o;
+        d_d = stage_d;
+    }
+    hipLaunchKernelGGL(k_load_rays, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_o, d_d, device_scene(ctx), q, n, counters,
+                       inline_counters(ctx));
+    HIP_TRY_LITERAL(ctx, hipGetLastError());
+    ctx->launch_spill = reinterpret_cast<uint2*>(base + kScratchSpill);
+    ctx->launch_max_threads = spill_threads;
+    const bool opt_time = ctx->opt_time;
+    ctx->opt_time = false;  // timing a launch creates events
+    const int rc = launch_trace(ctx, q, counters, counters + 2);
+    ctx->opt_time = opt_time;
+    ctx->launch_spill = nullptr;
+    ctx->launch_max_threads = 0;
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_hit_records, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, q.hit_t, q.hit_id, records, n);
+    HIP_TRY_LITERAL(ctx, hipGetLastError());
+    HIP_TRY_LITERAL(ctx, hipMemcpyAsync(out, records, n_rays * sizeof(RtHitRecord),
+                                        on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY_LITERAL(ctx, hipStreamSynchronize(ctx->stream));
+    return harvest(ctx);
 }
 
 int rt_self_test(RtContext* ctx, uint32_t which, uint64_t n_cases, uint64_t* failures) {

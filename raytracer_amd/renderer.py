@@ -176,6 +176,17 @@ class Renderer:
                                             origins.shape[0], out.ctypes.data))
         return out
 
+    def trace_rays_noalloc(self, origins, directions) -> np.ndarray:
+        """rt_trace_rays_noalloc: the same answers out of the library's fixed scratch
+        array, without any allocation on the device (at most 524288 rays)."""
+        origins = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        directions = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        assert origins.shape == directions.shape
+        out = np.zeros(origins.shape[0], dtype=HIT_DT)
+        self._check(self._lib.rt_trace_rays_noalloc(self._ctx, origins.ctypes.data, directions.ctypes.data,
+                                                    origins.shape[0], out.ctypes.data, 0))
+        return out
+
     def self_test_division(self, n_cases: int = 1 << 28) -> int:
         """Number of quotients (of about n_cases) on which the kernels' shared-
         reciprocal division differs from IEEE division; 0 on a correct build."""
