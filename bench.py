@@ -38,19 +38,38 @@ from raytracer_amd.scene import Scene  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, spec
 
 
-def recorded_traffic(args):
-    """Memory-side bytes per launch of the traversal kernel, from the hardware-
-    counter passes recorded in profiles/ (tools/pmc_profile.sh + tools/pmc_traffic.py:
-    FETCH_SIZE doubled as measured for 128-B requests on gfx950, plus WRITE_SIZE).
-    Counters cannot be collected inside a timed run, so the figure is the one
-    recorded for this same workload, or None when the workload differs."""
-    if (args.workload, args.width, args.height, args.spp, args.bounces, args.detail) != ("room", 1920, 1080, 256, 60, 4):
-        return None
+VALU_PEAK_GINSTR = 1024 * 2.4 / 2.0  # 1024 SIMDs x 2.4 GHz, one wave64 vector instruction per 2 cycles: 1228.8 G/s
+PROFILE = os.path.join(ROOT, "profiles", "r02_counters.json")
+
+
+def kernel_source_hash() -> str:
+    """Identifies the device code a counter profile belongs to: a hash over the
+    kernel sources and the build flags (the Makefile)."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "raytracer_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(base, "device", "*")) + [os.path.join(base, "Makefile")]):
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def recorded_counters(args):
+    """Hardware counters of the traversal kernel, per launch and per ray, from the
+    counter passes recorded in profiles/ (tools/pmc_profile.sh + tools/pmc_record.py;
+    counters cannot be collected inside a timed run).  Only a record made from these
+    very kernel sources and for this workload is used: otherwise None."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            return float(json.load(f)["bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
+        with open(PROFILE) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
         return None
+    if rec.get("source_hash") != kernel_source_hash():
+        return None
+    key = f"{args.workload}:{args.width}x{args.height}:b{args.bounces}:d{args.detail}:fast{int(args.fast)}"
+    return rec.get("workloads", {}).get(key)
 
 
 WORKLOADS = {
@@ -61,6 +80,10 @@ WORKLOADS = {
     # the room at 16384 x 16384 into the memory-mapped image file, tile by tile; a step is one
     # more one-sample pass over the whole image, resumed from the file (`continue`)
     "room16k": (16384, 16384, 1, 60),
+    # meshes the reference's own checkout holds (tests/golden/assets): boombox_4k.obj with the camera of
+    # scenes/boombox and generated 4096^2 textures in place of the two .ppm files the checkout lacks
+    "boombox": (2000, 2000, 64, 10),
+    "knight": (1920, 1080, 64, 10),  # "hollow knight.obj", framed from its bounding box (no scene file exists for it)
 }
 
 
@@ -79,6 +102,14 @@ def scene_text(args) -> tuple[str, str]:
         return (assets.blob_scene_text("blob", args.width, args.height, args.spp, args.bounces),
                 "bunny-class generated smooth mesh ({n} triangles, vertex normals, default grey Lambertian), "
                 "{w}x{h}, {spp} spp, {b} bounces, camera of scenes/bunny")
+    if args.workload == "boombox":
+        return (assets.reference_scene_text("boombox_4k", args.width, args.height, args.spp, args.bounces),
+                "the reference's obj/boombox_4k.obj ({n} triangles, two usemtl groups, generated 4096x4096 P6 textures "
+                "under the names its .mtl gives), {w}x{h}, {spp} spp, {b} bounces, screen and camera of scenes/boombox")
+    if args.workload == "knight":
+        return (assets.reference_scene_text("hollow knight", args.width, args.height, args.spp, args.bounces),
+                "the reference's obj/hollow knight.obj ({n} triangles, vertex normals, solid Kd materials) on a ground plane, "
+                "{w}x{h}, {spp} spp, {b} bounces, framed from its bounding box")
     return (assets.tree_scene_text("tree", args.width, args.height, args.spp, args.bounces),
             "island-tree-class generated tree ({n} triangles: overlapping leaf quads, textured island and bark), "
             "{w}x{h}, {spp} spp, {b} bounces, camera of scenes/island-tree")
@@ -102,6 +133,8 @@ def load_scene(args, renderer=None) -> Scene:
         assets.write_room(root, "room", detail=args.detail)
     elif args.workload == "blob" and not os.path.exists(os.path.join(root, "obj", "blob.obj")):
         assets.write_blob(root, "blob", subdivisions=min(8, 2 + args.detail))   # detail 4: 81,920 triangles
+    elif args.workload in ("boombox", "knight"):
+        assets.stage_reference_assets(root, texture_size=4096)
     elif args.workload == "tree" and not os.path.exists(os.path.join(root, "obj", "tree.obj")):
         assets.write_tree(root, "tree", n_leaves=125_000 * args.detail)          # detail 4: 1.04e6 triangles
     scene = parse(text, root, renderer=renderer)  # triangle BVH built on the GPU (same tree as the host builder's)
@@ -115,26 +148,39 @@ def load_scene(args, renderer=None) -> Scene:
 
 def cpu_baseline(scene: Scene, args) -> dict:
     """The CPU restatement of the reference's multithreaded renderer
-    (oracle/rt_oracle.c, pinned worker threads over pixel chunks), timed on this
-    box's host cores on a bounded sample of the same workload."""
+    (oracle/rt_oracle.c: T x T pixel chunks off an atomic counter, worker i pinned
+    to core i, /root/reference/src/lib.rs:195-235), compiled here for this machine
+    (-O3 -march=native, no FMA contraction, no fast-math) and timed on all the
+    cores this process may use, on a bounded sample of the same frame: every k-th
+    row of the whole image, so that the mix of paths is the frame's."""
+    import tempfile
+
     from oracle import binding as O
 
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    allowed = len(os.sched_getaffinity(0))
+    share = int(os.environ.get("OMP_NUM_THREADS", "0"))  # the box's CPU share for this job, when it states one
+    threads = min(allowed, share) if share > 0 else allowed
+    native = O.build_native(tempfile.mkdtemp(prefix="rt_oracle_native_"))
+    library = O.lib(native) if native else O.lib()
     p = scene.params.copy()
-    p.tile_w, p.tile_h = min(args.width // 2, 960), min(args.height // 2, 540)
-    p.tile_x, p.tile_y = (args.width - p.tile_w) // 2, (args.height - p.tile_h) // 2
+    p.tile_x = p.tile_y = p.tile_w = p.tile_h = 0
     p.has_continue = p.continue_sampling = p.incremental = 0
+    stride = max(1, args.height // 60)  # about 60 rows spread over the frame
     t0 = time.perf_counter()
-    O.render_sums(scene, p, 0, 1, threads=threads)
+    O.render_sums_rows(scene, p, 0, 1, stride, threads=threads, library=library)
     probe = time.perf_counter() - t0
-    spp = int(max(1, min(64, round(15.0 / max(probe, 1e-3)))))  # aim at about 15 s of CPU work
+    spp = int(max(1, min(256, round(15.0 / max(probe, 1e-3)))))  # aim at about 15 s of CPU work
     c = O.OracleCounters()
     t0 = time.perf_counter()
-    O.render_sums(scene, p, 1, spp, threads=threads, counters=c)
+    O.render_sums_rows(scene, p, 1, spp, stride, threads=threads, counters=c, library=library)
     dt = time.perf_counter() - t0
+    rows = (args.height + stride - 1) // stride
     return {"value": round(c.segments / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"centre {p.tile_w}x{p.tile_h} tile of the same frame, {spp} spp, {args.bounces} bounces: "
-                      f"{c.segments} rays in {dt:.1f}s",
+            "build": "gcc -O3 -march=native -ffp-contract=off, compiled on this host" if native
+                     else "prebuilt -O2 library (no compiler on this host)",
+            "host_cpus_visible": os.cpu_count(), "cpus_allowed": allowed,
+            "sample": f"every {stride}th row of the same frame ({rows} rows x {args.width} pixels), {spp} spp, "
+                      f"{args.bounces} bounces: {c.segments} rays in {dt:.1f}s on {threads} pinned threads",
             "rays_per_sample": round(c.segments / max(c.paths, 1), 3)}
 
 
@@ -155,6 +201,9 @@ def main() -> None:
     ap.add_argument("--shade-groups", type=int, default=None, help="shading workgroups per CU (library default: 8)")
     ap.add_argument("--chains", type=int, default=None, help="independent chains a batch is split into (library default: 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fast", action="store_true",
+                    help="RT_OPT_FAST_SLAB: reciprocal-direction slab test with fused multiply-add (not bit-exact; the line "
+                         "then carries the mismatch figures against the exact mode)")
     ap.add_argument("--exact", action="store_true",
                     help="with several GPUs: hand the running sums from rank to rank in sample order instead of one "
                          "reduce, so that the image is the single-GPU image bit for bit")
@@ -276,6 +325,33 @@ def main() -> None:
     S, P, H = cs["prim_tests"][0] / seg, cs["prim_tests"][1] / seg, cs["hits"] / seg
     rays_per_path = cs["segments"] / max(cs["paths"], 1)
 
+    # ---- the fast slab test against the exact mode on this very frame (untimed)
+    fast_report = None
+    if args.fast and not tiled:
+        check_spp = min(args.spp, 8)
+        exact_hits = r.trace_primary(params, 0, True)
+        exact_sums = r.render_sums(params, 0, check_spp)
+        r.set_option(F.RT_OPT_FAST_SLAB, 1)
+        fast_hits = r.trace_primary(params, 0, True)
+        fast_sums = r.render_sums(params, 0, check_spp)
+        differ = (exact_hits["kind"] != fast_hits["kind"]) | (exact_hits["prim"] != fast_hits["prim"])
+        same_id = ~differ
+        mean_e, mean_f = exact_sums / check_spp, fast_sums / check_spp
+        err = (mean_f - mean_e).astype(np.float64)
+        img_e, img_f = r.resolve(params, exact_sums, check_spp), r.resolve(params, fast_sums, check_spp)
+        fast_report = {
+            "primary_hit_id_mismatch_rate": float(differ.mean()), "primary_hit_id_mismatches": int(differ.sum()),
+            "primary_hit_distance_bits_differ_where_id_equal": int((exact_hits["t"].view(np.uint32)[same_id]
+                                                                    != fast_hits["t"].view(np.uint32)[same_id]).sum()),
+            "pixels": int(differ.size), "spp_compared": check_spp,
+            "radiance_values_differing": int((exact_sums.view(np.uint32) != fast_sums.view(np.uint32)).sum()),
+            "radiance_rmse": float(np.sqrt(np.mean(err ** 2))), "radiance_max_abs": float(np.abs(err).max()),
+            "u8_max_abs": int(np.abs(img_e.astype(np.int16) - img_f.astype(np.int16)).max()),
+            "u8_values_differing": int((img_e != img_f).sum()),
+        }
+    elif args.fast:
+        r.set_option(F.RT_OPT_FAST_SLAB, 1)
+
     for _ in range(args.warmup):
         step()
     r.set_option(F.RT_OPT_TIME_KERNELS, 1)
@@ -314,9 +390,69 @@ def main() -> None:
         trace_bytes_per_ray = 72.0 * B + 36.0 * T + 24.0 + 2 * 12.0
         whole_bytes_per_ray = 72.0 * B + 36.0 * T + 24.0 * S + 32.0 * P + 120.0 + 140.0 * H + 24.0 / rays_per_path
         my_trace_ms, my_launches, my_segments = st["trace_ms"], max(st["trace_launches"], 1), st["segments"]
-        achieved = trace_bytes_per_ray * my_segments / (my_trace_ms / 1e3) / 1e9 if my_trace_ms > 0 else 0.0
+        avg_launch_s = my_trace_ms / 1e3 / my_launches
+        rays_per_launch = my_segments / my_launches
+        algorithmic_gbs = trace_bytes_per_ray * my_segments / (my_trace_ms / 1e3) / 1e9 if my_trace_ms > 0 else 0.0
         rays_per_s = segments / dt
-        traffic = recorded_traffic(args)
+        rec = recorded_counters(args)
+        # The traversal kernel's working set (branch records, triangles) lives in LDS, L2 and the
+        # Infinity Cache, so HBM does not bound it; vector-instruction issue does.  Roof: every SIMD
+        # issuing one wave64 vector instruction per 2 cycles at 2.4 GHz.  Instructions per ray come from
+        # the hardware-counter passes recorded for these kernel sources (SQ_INSTS_VALU per launch over
+        # the rays of the launch); without a matching record the figures are null.
+        roofline = {
+            "bound": "valu_issue",
+            "kernel": "k_trace<TRIANGLE>",
+            "unit": "G wave-instr/s",
+            "peak": VALU_PEAK_GINSTR,
+            "achieved": None, "frac": None, "traffic": None,
+            "avg_launch_ms": round(avg_launch_s * 1e3, 4),
+            "launches": int(my_launches),
+            "rays_per_launch": round(rays_per_launch),
+            # a batch runs as `chains` independent chains whose traversal launches are resident side by side,
+            # each on its share of the wave slots
+            "launch_concurrency": chains,
+            "kernel_time_share": round(my_trace_ms / 1e3 / dt, 4),
+            "per_ray": {"branch_visits": round(B, 3), "triangle_tests": round(T, 3), "sphere_tests": round(S, 3),
+                        "plane_tests": round(P, 3), "hit_fraction": round(H, 4)},
+            # the byte roofline on the reference's data sizes, visit by visit: reported, not binding
+            "algorithmic_hbm": {"binding": False, "bytes_per_ray": round(trace_bytes_per_ray, 1),
+                                "bytes_per_launch": round(trace_bytes_per_ray * rays_per_launch),
+                                "achieved_GBps_per_launch": round(algorithmic_gbs, 2), "peak_GBps": HBM_PEAK_GBS,
+                                "whole_path_bytes_per_ray": round(whole_bytes_per_ray, 1),
+                                "whole_path_GBps_over_wall": round(rays_per_s * whole_bytes_per_ray / 1e9, 2)},
+        }
+        if rec is not None and avg_launch_s > 0:
+            ipr = rec["trace"]["valu_insts_per_ray"]
+            per_launch = ipr * rays_per_launch / avg_launch_s / 1e9
+            over_wall = ipr * my_segments / dt / 1e9  # this rank's traversal launches together, per second of the timed region
+            roofline.update({
+                # definition: one launch's instructions over its own duration (HIP events on the launch's stream)
+                "achieved": round(per_launch, 2),
+                "frac": round(per_launch / VALU_PEAK_GINSTR, 5),
+                # with `launch_concurrency` launches resident together, the machine issues for all of them:
+                "achieved_all_launches_over_wall": round(over_wall, 2),
+                "frac_all_launches_over_wall": round(over_wall / VALU_PEAK_GINSTR, 5),
+                "valu_insts_per_ray": round(ipr, 3),
+                "valu_insts_per_launch": round(ipr * rays_per_launch),
+                "salu_per_valu": rec["trace"].get("salu_per_valu"),
+                "lanes_per_valu_inst": rec["trace"].get("lanes_per_valu_inst"),
+                "valu_busy_alone": rec["trace"].get("valu_busy"),
+                "lds_bank_conflict_share": rec["trace"].get("lds_bank_conflict_share"),
+                # measured memory-side bytes per launch (FETCH_SIZE with its gfx950 correction + WRITE_SIZE), and
+                # what they are of the HBM peak over the launch's duration
+                "traffic": rec["trace"].get("hbm_bytes_per_launch"),
+                "traffic_unit": "bytes per launch (memory-side counters of the recorded profile, scaled to this run's rays per launch)",
+                "traffic_frac_of_hbm_peak": None,
+                "profile": {"file": os.path.relpath(PROFILE, ROOT), "source_hash": kernel_source_hash()},
+            })
+            if rec["trace"].get("hbm_bytes_per_ray") is not None:
+                traffic = rec["trace"]["hbm_bytes_per_ray"] * rays_per_launch
+                roofline["traffic"] = round(traffic)
+                roofline["traffic_frac_of_hbm_peak"] = round(traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS, 5)
+        else:
+            roofline["note"] = ("no counter record for these kernel sources and this workload in profiles/: "
+                                "run tools/pmc_profile.sh and tools/pmc_record.py")
         out = {
             "metric": "Mrays/s (all bounces) breakfast-room 1080p" if args.workload == "room" else f"Mrays/s (all bounces) {args.workload}",
             "value": round(rays_per_s / 1e6, 3),
@@ -337,41 +473,18 @@ def main() -> None:
                 "collective": ("none (each rank writes its tiles into the mapped file)" if tiled
                                else "chain of send/recv of f32 radiance per step (exact fold)" if args.exact
                                else "reduce(sum) of f32 radiance per step") if world > 1 else "none",
+                "arithmetic": "fast slab test (reciprocal direction, fused multiply-add): not bit-exact" if args.fast
+                              else "exact (bit-identical to the CPU oracle)",
             },
+            "bench_args": {"workload": args.workload, "width": args.width, "height": args.height, "spp": args.spp,
+                           "bounces": args.bounces, "detail": args.detail, "chains": chains},
             "samples_per_s": round(paths / dt, 1),
             "image_repeats": repeatable,  # an extra, untimed step stored the same bytes as the last timed one
             "rays_per_sample": round(rays_per_path, 3),
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "k_trace<TRIANGLE>",
-                "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": traffic,
-                "traffic_unit": "bytes per launch (memory-side counters, recorded profile)",
-                # algorithmic bytes are counted on the reference's data sizes, visit by visit; the tree and
-                # the triangles stay in LDS and L2, so the HBM traffic is a small part of them and `frac`
-                # can pass 1: the kernel is bound by instruction issue, not by this roofline
-                "note": "cache-resident working set: compare algorithmic_bytes_per_launch with traffic",
-                "algorithmic_bytes_per_launch": round(trace_bytes_per_ray * my_segments / my_launches),
-                "bytes_per_ray": round(trace_bytes_per_ray, 1),
-                "avg_launch_ms": round(my_trace_ms / my_launches, 4),
-                "launches": int(my_launches),
-                # A batch runs as `chains` independent chains whose traversal launches are resident side by
-                # side, each on its share of the wave slots: `achieved` is the rate of one launch (the
-                # definition: its bytes / its duration); all launches together move at least this much per
-                # second of wall time on the device:
-                "launch_concurrency": chains,
-                "achieved_all_launches_over_wall": round(trace_bytes_per_ray * my_segments / dt / 1e9, 2),
-                "kernel_time_share": round(my_trace_ms / 1e3 / dt, 4),
-                "per_ray": {"branch_visits": round(B, 3), "triangle_tests": round(T, 3), "sphere_tests": round(S, 3),
-                            "plane_tests": round(P, 3), "hit_fraction": round(H, 4)},
-                "whole_path": {"bytes_per_ray": round(whole_bytes_per_ray, 1),
-                               "achieved": round(rays_per_s * whole_bytes_per_ray / 1e9, 2),
-                               "frac": round(rays_per_s * whole_bytes_per_ray / 1e9 / (HBM_PEAK_GBS * world), 5)},
-            },
+            "roofline": roofline,
         }
+        if fast_report is not None:
+            out["fast_mode_vs_exact"] = fast_report
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, args)
         print(json.dumps(out), flush=True)

@@ -228,6 +228,13 @@ typedef enum RtOption {
     RT_OPT_TRACE_REFILL_MIN = 11, /* idle lanes of a wave that trigger a refill from the queue (1..64) */
     RT_OPT_CHAINS = 13,         /* 1..4: independent chains (own queues, own stream) a large batch of paths is split into; each chain's tails and launch gaps are filled by the others (default 2) */
     RT_OPT_SHADE_GROUPS_PER_CU = 14, /* grid of the shading kernel: workgroups of 256 threads per compute unit (1..64, default 8) */
+    /* 0/1, default 0.  NOT bit-exact when on: the triangle family's ray/box test
+     * (/root/reference/src/bvh.rs:25-43) multiplies by the reciprocal of the direction,
+     * fused with the subtraction, instead of dividing.  Box distances then differ from the
+     * reference's in their last places, which can reorder visits and flip a cull where a box
+     * and the closest hit are equally far to rounding; hit distances themselves, triangle
+     * tests and shading stay exact.  Ignored while RT_OPT_COUNT_TRAVERSAL is on. */
+    RT_OPT_FAST_SLAB = 15,
     RT_OPT_TRACE_WAVES_PER_CU = 12 /* traversal waves resident per compute unit (0 = as many as fit, else 1..32): leaves room for kernels of another context on the same GPU */
 } RtOption;
 

@@ -33,49 +33,76 @@ def build() -> str:
     return _LIB_PATH
 
 
+def build_native(out_dir: str) -> str | None:
+    """The same source compiled for the machine this runs on (-O3 -march=native,
+    still without FMA contraction or fast-math: same results), as the timed CPU
+    baseline wants it.  Returns the library's path, or None when no compiler is at hand."""
+    out = os.path.join(out_dir, "librt_oracle_native.so")
+    cmd = ["gcc", "-std=gnu11", "-O3", "-march=native", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+           "-fno-unsafe-math-optimizations", f"-I{os.path.join(os.path.dirname(_HERE), 'include')}", "-shared", "-o", out,
+           os.path.join(_HERE, "rt_oracle.c"), "-lm", "-lpthread"]
+    try:
+        subprocess.run(cmd, check=True, capture_output=True, timeout=120)
+    except (OSError, subprocess.SubprocessError):
+        return None
+    return out
+
+
 _lib = None
+_libs = {}
 
 
-def lib() -> C.CDLL:
+def lib(path: str | None = None) -> C.CDLL:
+    """The oracle library: the -O2 build next to this file, or the one at `path`."""
     global _lib
+    if path is not None:
+        if path not in _libs:
+            _libs[path] = _declare(C.CDLL(path))
+        return _libs[path]
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             build()
-        L = C.CDLL(_LIB_PATH)
-        P = C.POINTER
-        L.oracle_rng_u64.restype, L.oracle_rng_u64.argtypes = F.u64, [P(F.u64)]
-        L.oracle_rng_f32.restype, L.oracle_rng_f32.argtypes = F.f32, [P(F.u64)]
-        L.oracle_render_sums.restype = C.c_int
-        L.oracle_render_sums.argtypes = [P(F.RtSceneDesc), P(F.RtRenderParams), F.u32, F.u32, C.c_void_p,
-                                         C.c_int, P(OracleCounters)]
-        L.oracle_render.restype = C.c_int
-        L.oracle_render.argtypes = [P(F.RtSceneDesc), P(F.RtRenderParams), C.c_void_p, C.c_void_p, C.c_int,
-                                    P(OracleCounters)]
-        L.oracle_resolve.restype = C.c_int
-        L.oracle_resolve.argtypes = [P(F.RtRenderParams), C.c_void_p, F.u32, C.c_int, F.u32, C.c_void_p]
-        L.oracle_trace_primary.restype = C.c_int
-        L.oracle_trace_primary.argtypes = [P(F.RtSceneDesc), P(F.RtRenderParams), F.u32, C.c_int, C.c_void_p,
-                                           P(OracleCounters)]
-        L.oracle_trace_rays.restype = C.c_int
-        L.oracle_trace_rays.argtypes = [P(F.RtSceneDesc), C.c_void_p, C.c_void_p, F.u64, C.c_void_p,
-                                        P(OracleCounters)]
-        for name, shape in (("oracle_sphere_hit", F.RtSphere), ("oracle_plane_hit", F.RtPlane),
-                            ("oracle_triangle_hit", F.RtTriangle), ("oracle_box_hit", F.RtNode)):
-            fn = getattr(L, name)
-            fn.restype, fn.argtypes = C.c_int, [P(shape), P(F.f32 * 3), P(F.f32 * 3), P(F.f32)]
-        L.oracle_color_sample.restype = None
-        L.oracle_color_sample.argtypes = [P(F.RtSceneDesc), F.u32, P(F.f32 * 2), P(F.f32 * 3)]
-        L.oracle_scatter.restype = C.c_int
-        L.oracle_scatter.argtypes = [P(F.RtSceneDesc), F.u32, P(F.f32 * 3), P(F.f32 * 3), P(F.f32 * 3),
-                                     P(F.u64), P(F.f32 * 3), P(F.f32 * 3)]
-        L.oracle_surface_at.restype = None
-        L.oracle_surface_at.argtypes = [P(F.RtSceneDesc), P(F.RtHitRecord), P(F.f32 * 3), P(F.f32 * 3),
-                                        P(F.f32 * 2), P(F.u32)]
-        L.oracle_ray_color.restype = None
-        L.oracle_ray_color.argtypes = [P(F.RtSceneDesc), P(F.f32 * 3), P(F.f32 * 3), F.u32, P(F.u64),
-                                       P(F.f32 * 3)]
-        _lib = L
+        _lib = _declare(C.CDLL(_LIB_PATH))
     return _lib
+
+
+def _declare(L: C.CDLL) -> C.CDLL:
+    P = C.POINTER
+    L.oracle_rng_u64.restype, L.oracle_rng_u64.argtypes = F.u64, [P(F.u64)]
+    L.oracle_rng_f32.restype, L.oracle_rng_f32.argtypes = F.f32, [P(F.u64)]
+    L.oracle_render_sums.restype = C.c_int
+    L.oracle_render_sums.argtypes = [P(F.RtSceneDesc), P(F.RtRenderParams), F.u32, F.u32, C.c_void_p,
+                                     C.c_int, P(OracleCounters)]
+    L.oracle_render_sums_rows.restype = C.c_int
+    L.oracle_render_sums_rows.argtypes = [P(F.RtSceneDesc), P(F.RtRenderParams), F.u32, F.u32, F.u32, C.c_void_p,
+                                          C.c_int, P(OracleCounters)]
+    L.oracle_render.restype = C.c_int
+    L.oracle_render.argtypes = [P(F.RtSceneDesc), P(F.RtRenderParams), C.c_void_p, C.c_void_p, C.c_int,
+                                P(OracleCounters)]
+    L.oracle_resolve.restype = C.c_int
+    L.oracle_resolve.argtypes = [P(F.RtRenderParams), C.c_void_p, F.u32, C.c_int, F.u32, C.c_void_p]
+    L.oracle_trace_primary.restype = C.c_int
+    L.oracle_trace_primary.argtypes = [P(F.RtSceneDesc), P(F.RtRenderParams), F.u32, C.c_int, C.c_void_p,
+                                       P(OracleCounters)]
+    L.oracle_trace_rays.restype = C.c_int
+    L.oracle_trace_rays.argtypes = [P(F.RtSceneDesc), C.c_void_p, C.c_void_p, F.u64, C.c_void_p,
+                                    P(OracleCounters)]
+    for name, shape in (("oracle_sphere_hit", F.RtSphere), ("oracle_plane_hit", F.RtPlane),
+                        ("oracle_triangle_hit", F.RtTriangle), ("oracle_box_hit", F.RtNode)):
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = C.c_int, [P(shape), P(F.f32 * 3), P(F.f32 * 3), P(F.f32)]
+    L.oracle_color_sample.restype = None
+    L.oracle_color_sample.argtypes = [P(F.RtSceneDesc), F.u32, P(F.f32 * 2), P(F.f32 * 3)]
+    L.oracle_scatter.restype = C.c_int
+    L.oracle_scatter.argtypes = [P(F.RtSceneDesc), F.u32, P(F.f32 * 3), P(F.f32 * 3), P(F.f32 * 3),
+                                 P(F.u64), P(F.f32 * 3), P(F.f32 * 3)]
+    L.oracle_surface_at.restype = None
+    L.oracle_surface_at.argtypes = [P(F.RtSceneDesc), P(F.RtHitRecord), P(F.f32 * 3), P(F.f32 * 3),
+                                    P(F.f32 * 2), P(F.u32)]
+    L.oracle_ray_color.restype = None
+    L.oracle_ray_color.argtypes = [P(F.RtSceneDesc), P(F.f32 * 3), P(F.f32 * 3), F.u32, P(F.u64),
+                                   P(F.f32 * 3)]
+    return L
 
 
 def _vec3(v):
@@ -104,6 +131,19 @@ def render_sums(scene: Scene, params, sample_begin: int, sample_count: int, thre
                                   threads, C.byref(counters) if counters is not None else None)
     if rc:
         raise RuntimeError(f"oracle_render_sums failed ({rc})")
+    return out
+
+
+def render_sums_rows(scene: Scene, params, sample_begin: int, sample_count: int, row_stride: int, threads: int = 1,
+                     counters: OracleCounters | None = None, library: C.CDLL | None = None) -> np.ndarray:
+    """render_sums over every `row_stride`-th row of the region only."""
+    h, w = params.tile_shape()
+    out = np.zeros(((h + row_stride - 1) // row_stride, w, 3), dtype=np.float32)
+    d = scene.desc()
+    rc = (library or lib()).oracle_render_sums_rows(C.byref(d), C.byref(params), sample_begin, sample_count, row_stride,
+                                                    out.ctypes.data, threads, C.byref(counters) if counters is not None else None)
+    if rc:
+        raise RuntimeError(f"oracle_render_sums_rows failed ({rc})")
     return out
 
 

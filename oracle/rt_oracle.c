@@ -545,6 +545,7 @@ typedef struct {
     OracleCounters counters;
     int count;
     int cpu;
+    uint32_t row_stride; /* every row_stride-th row of the region is rendered (1 = all) */
 } Worker;
 
 /* The reference's worker body (src/lib.rs:219-297) for one pass: take pixel
@@ -570,7 +571,7 @@ static void* worker_main(void* arg) {
         if (end > w->n_pixels) end = w->n_pixels;
         for (size_t i = begin; i < end; ++i) {
             const uint32_t x = w->frame.x0 + (uint32_t)(i % w->frame.tw);
-            const uint32_t y = w->frame.y0 + (uint32_t)(i / w->frame.tw);
+            const uint32_t y = w->frame.y0 + (uint32_t)(i / w->frame.tw) * w->row_stride;
             pixel_sum(&tr, w->params, &w->frame, x, y, w->s0, w->n, NULL, &w->sums[3 * i]);
         }
     }
@@ -590,12 +591,24 @@ static void add_counters(OracleCounters* dst, const OracleCounters* src) {
  * sub-stream mode, on `n_threads` pinned workers with the reference's chunking
  * (T*T chunks of W*H/(T*T) pixels, src/lib.rs:195-204).  `counters` may be
  * NULL. */
+int oracle_render_sums_rows(const RtSceneDesc* scene, const RtRenderParams* p, uint32_t sample_begin,
+                            uint32_t sample_count, uint32_t row_stride, float* sums, int n_threads,
+                            OracleCounters* counters);
 int oracle_render_sums(const RtSceneDesc* scene, const RtRenderParams* p, uint32_t sample_begin,
                        uint32_t sample_count, float* sums, int n_threads, OracleCounters* counters) {
-    if (p->rng_mode != RT_RNG_SUBSTREAM) return -1;
+    return oracle_render_sums_rows(scene, p, sample_begin, sample_count, 1, sums, n_threads, counters);
+}
+
+/* The same over every `row_stride`-th row of the region only (rows y0, y0 +
+ * row_stride, ...): `sums` holds ceil(rows / row_stride) rows.  A sample of the
+ * whole frame for timing: the mix of paths is the frame's, the work a fraction. */
+int oracle_render_sums_rows(const RtSceneDesc* scene, const RtRenderParams* p, uint32_t sample_begin,
+                            uint32_t sample_count, uint32_t row_stride, float* sums, int n_threads,
+                            OracleCounters* counters) {
+    if (p->rng_mode != RT_RNG_SUBSTREAM || row_stride == 0) return -1;
     if (n_threads < 1) n_threads = 1;
     const Frame f = make_frame(p);
-    const size_t n_pixels = (size_t)f.tw * f.th;
+    const size_t n_pixels = (size_t)f.tw * ((f.th + row_stride - 1) / row_stride);
     size_t chunk_size = n_pixels / ((size_t)n_threads * (size_t)n_threads);
     if (chunk_size == 0) chunk_size = 1; /* the reference would panic here */
     const size_t n_chunks = (n_pixels + chunk_size - 1) / chunk_size;
@@ -610,6 +623,7 @@ int oracle_render_sums(const RtSceneDesc* scene, const RtRenderParams* p, uint32
         ws[i].next_chunk = &next; ws[i].chunk_size = chunk_size; ws[i].n_chunks = n_chunks;
         ws[i].n_pixels = n_pixels; ws[i].count = counters != NULL;
         ws[i].cpu = n_threads > 1 ? i : -1;
+        ws[i].row_stride = row_stride;
     }
     if (n_threads == 1) {
         worker_main(&ws[0]);

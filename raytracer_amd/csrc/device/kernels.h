@@ -348,7 +348,15 @@ __host__ __device__ inline size_t trace_lds_per_wave(uint32_t lds_slots) {
 
 // Eight waves per SIMD leave each wave 96 scalar registers, of which the
 // system's trap handler keeps 16: the kernel is held to the 80 that remain.
-template <int KIND, bool COUNT, bool SHARE, int WAVES>
+//
+// FASTSLAB (an option, off by default, not bit-exact): the slab test of an ordinary
+// ray multiplies by the reciprocal of the direction instead of dividing, fused:
+// t = fma(bound, 1/d, -origin/d), six packed instructions for the twelve values in
+// place of thirty.  Distances of boxes then differ from the reference's in the last
+// places, which can change the order of visits and the outcome of a cull where a
+// box's distance and the closest hit's agree to rounding; triangle tests and
+// everything else stay exact.
+template <int KIND, bool COUNT, bool SHARE, int WAVES, bool FASTSLAB = false>
 __global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(COUNT ? 4 : 8))) k_trace(TraceArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     float4* const s_nodes = reinterpret_cast<float4*>(s_raw);
@@ -468,9 +476,16 @@ __global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num
                                      (int(o.y == 0.0f) | int(magnitude_in(o.y, 0x1p-60f, 0x1p59f))) &
                                      (int(o.z == 0.0f) | int(magnitude_in(o.z, 0x1p-60f, 0x1p59f)));
                     fast = (int(a.bounds_fast != 0) & d_ok & o_ok) != 0;
-                    zx = reciprocal_of(d.x);
-                    zy = reciprocal_of(d.y);
-                    zz = reciprocal_of(d.z);
+                    if (FASTSLAB) {
+                        // hi = 1/d, lo = -o/d (as -(o * (1/d)))
+                        zx.hi = 1.0f / d.x; zx.lo = -(o.x * zx.hi);
+                        zy.hi = 1.0f / d.y; zy.lo = -(o.y * zy.hi);
+                        zz.hi = 1.0f / d.z; zz.lo = -(o.z * zz.hi);
+                    } else {
+                        zx = reciprocal_of(d.x);
+                        zy = reciprocal_of(d.y);
+                        zz = reciprocal_of(d.z);
+                    }
                 }
                 pool_next += take;
             }
@@ -523,10 +538,22 @@ __global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num
                 float d0, d1;
                 bool h0, h1;
                 if (fast) {
-                    const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
-                    const v2f t1x = div_by2(v2f{qx.x, qx.y} - ox, d.x, zx), t2x = div_by2(v2f{qx.z, qx.w} - ox, d.x, zx);
-                    const v2f t1y = div_by2(v2f{qy.x, qy.y} - oy, d.y, zy), t2y = div_by2(v2f{qy.z, qy.w} - oy, d.y, zy);
-                    const v2f t1z = div_by2(v2f{qz.x, qz.y} - oz, d.z, zz), t2z = div_by2(v2f{qz.z, qz.w} - oz, d.z, zz);
+                    v2f t1x, t2x, t1y, t2y, t1z, t2z;
+                    if (FASTSLAB) {
+                        const v2f ix = {zx.hi, zx.hi}, iy = {zy.hi, zy.hi}, iz = {zz.hi, zz.hi};
+                        const v2f nx = {zx.lo, zx.lo}, ny = {zy.lo, zy.lo}, nz = {zz.lo, zz.lo};
+                        t1x = __builtin_elementwise_fma(v2f{qx.x, qx.y}, ix, nx);
+                        t2x = __builtin_elementwise_fma(v2f{qx.z, qx.w}, ix, nx);
+                        t1y = __builtin_elementwise_fma(v2f{qy.x, qy.y}, iy, ny);
+                        t2y = __builtin_elementwise_fma(v2f{qy.z, qy.w}, iy, ny);
+                        t1z = __builtin_elementwise_fma(v2f{qz.x, qz.y}, iz, nz);
+                        t2z = __builtin_elementwise_fma(v2f{qz.z, qz.w}, iz, nz);
+                    } else {
+                        const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+                        t1x = div_by2(v2f{qx.x, qx.y} - ox, d.x, zx), t2x = div_by2(v2f{qx.z, qx.w} - ox, d.x, zx);
+                        t1y = div_by2(v2f{qy.x, qy.y} - oy, d.y, zy), t2y = div_by2(v2f{qy.z, qy.w} - oy, d.y, zy);
+                        t1z = div_by2(v2f{qz.x, qz.y} - oz, d.z, zz), t2z = div_by2(v2f{qz.z, qz.w} - oz, d.z, zz);
+                    }
                     d0 = fmaxf(fmaxf(fminf(t1x.x, t2x.x), fminf(t1y.x, t2y.x)), fminf(t1z.x, t2z.x));
                     d1 = fmaxf(fmaxf(fminf(t1x.y, t2x.y), fminf(t1y.y, t2y.y)), fminf(t1z.y, t2z.y));
                     const float f0 = fminf(fminf(fmaxf(t1x.x, t2x.x), fmaxf(t1y.x, t2y.x)), fmaxf(t1z.x, t2z.x));

@@ -123,7 +123,7 @@ struct RtContext {
     uint32_t tune_waves = 8;        // waves per traversal workgroup (1, 8 or 16)
     uint32_t tune_cache_nodes = 144;  // branch records each multi-wave workgroup copies to LDS
     bool tune_share = true;  // deal pending (ray, triangle) pairs out to all lanes
-    bool opt_count = false, opt_time = false;
+    bool opt_count = false, opt_time = false, opt_fast_slab = false;
     uint64_t opt_samples_in_flight = 0;  // 0 = automatic
     std::vector<hipEvent_t> events;      // pairs around timed launches
     size_t events_used = 0;
@@ -445,9 +445,9 @@ unsigned long long* inline_counters(RtContext* ctx) { return ctx->opt_count ? ct
 // Launch one traversal kernel variant over a grid that is exactly what the
 // device keeps resident for its register and LDS use (the kernel is persistent:
 // its waves loop until the queue is drained).
-template <int KIND, bool COUNT, bool SHARE, int WAVES>
+template <int KIND, bool COUNT, bool SHARE, int WAVES, bool FASTSLAB = false>
 int launch_trace_variant(RtContext* ctx, TraceArgs a) {
-    const void* fn = reinterpret_cast<const void*>(&k_trace<KIND, COUNT, SHARE, WAVES>);
+    const void* fn = reinterpret_cast<const void*>(&k_trace<KIND, COUNT, SHARE, WAVES, FASTSLAB>);
     const int block = kTraceBlock * WAVES;
     a.cache_nodes = WAVES > 1 ? std::min(ctx->tune_cache_nodes, ctx->fam[KIND].n_branches) : 0u;
     const size_t lds = static_cast<size_t>(a.cache_nodes) * sizeof(DNode) + WAVES * trace_lds_per_wave(a.lds_slots);
@@ -477,7 +477,7 @@ int launch_trace_variant(RtContext* ctx, TraceArgs a) {
     if (grid == 0) return fail(ctx, RT_ERR_INVALID, "stack overflow area too small for one traversal workgroup");
     a.spill_stride = grid * static_cast<uint32_t>(block);
     if (a.spill_stride > thread_limit) return fail(ctx, RT_ERR_INVALID, "traversal grid larger than the stack overflow area");
-    hipLaunchKernelGGL((k_trace<KIND, COUNT, SHARE, WAVES>), dim3(grid), dim3(block), lds, ctx->launch_stream, a);
+    hipLaunchKernelGGL((k_trace<KIND, COUNT, SHARE, WAVES, FASTSLAB>), dim3(grid), dim3(block), lds, ctx->launch_stream, a);
     return RT_OK;
 }
 
@@ -486,6 +486,14 @@ int launch_trace_kind(RtContext* ctx, const TraceArgs& a) {
     if constexpr (KIND == 2) {
         // the triangle family: shared shape step, optionally several waves per workgroup
         if (ctx->tune_share) {
+            // the reciprocal slab test exists for the uncounted kernels of the triangle family
+            if (ctx->opt_fast_slab && !ctx->opt_count) {
+                switch (ctx->tune_waves) {
+                    case 8: return launch_trace_variant<2, false, true, 8, true>(ctx, a);
+                    case 16: return launch_trace_variant<2, false, true, 16, true>(ctx, a);
+                    default: return launch_trace_variant<2, false, true, 1, true>(ctx, a);
+                }
+            }
             switch (ctx->tune_waves) {
                 case 8: return ctx->opt_count ? launch_trace_variant<2, true, true, 8>(ctx, a) : launch_trace_variant<2, false, true, 8>(ctx, a);
                 case 16: return ctx->opt_count ? launch_trace_variant<2, true, true, 16>(ctx, a) : launch_trace_variant<2, false, true, 16>(ctx, a);
@@ -924,6 +932,7 @@ int rt_set_option(RtContext* ctx, uint32_t option, uint64_t value) {
     switch (option) {
         case RT_OPT_COUNT_TRAVERSAL: ctx->opt_count = value != 0; return RT_OK;
         case RT_OPT_TIME_KERNELS: ctx->opt_time = value != 0; return RT_OK;
+        case RT_OPT_FAST_SLAB: ctx->opt_fast_slab = value != 0; return RT_OK;
         case RT_OPT_SAMPLES_IN_FLIGHT: ctx->opt_samples_in_flight = value; return RT_OK;
         case RT_OPT_TRACE_LDS_SLOTS:
             if (value < 2 || value > 64) return fail(ctx, RT_ERR_INVALID, "lds slots must be in 2..64");

@@ -412,3 +412,30 @@ def test_malformed_descriptions_are_refused(renderer):
     with pytest.raises(RtError, match="triangles only"):
         renderer.upload(t)
     check_scene(renderer, s)  # the context stays usable
+
+
+def test_fast_slab_option_is_off_by_default_and_close_to_exact_when_on(renderer, asset_root):
+    # The reciprocal slab test is an explicit option outside the bit-exact contract: hit distances are
+    # still computed by the exact triangle test, so wherever the same primitive is found the distance
+    # bits are equal; primitives may differ only where two candidates are equally far to rounding.
+    s = scenes.room(asset_root, w=96, h=54, spp=4, bounces=12)
+    renderer.upload(s)
+    exact = renderer.trace_primary(s.params, 0, True)
+    exact_sums = renderer.render_sums(s.params, 0, 4)
+    assert_hits_equal(exact, O.trace_primary(s, s.params, 0, True))  # default = exact
+    renderer.set_option(F.RT_OPT_FAST_SLAB, 1)
+    try:
+        fast = renderer.trace_primary(s.params, 0, True)
+        fast_sums = renderer.render_sums(s.params, 0, 4)
+    finally:
+        renderer.set_option(F.RT_OPT_FAST_SLAB, 0)
+    same = (fast["kind"] == exact["kind"]) & (fast["prim"] == exact["prim"])
+    assert same.mean() > 0.999
+    assert np.array_equal(bits(fast["t"][same]), bits(exact["t"][same]))
+    # tolerance of the fast mode (not of the default): RMSE 1e-3 of the mean radiance at 4 spp on this
+    # small frame, where one diverging path moves a pixel visibly; the exact mode's tolerance stays 0
+    err = (fast_sums - exact_sums).astype(np.float64) / 4
+    assert np.sqrt(np.mean(err ** 2)) < 1e-2
+    assert (bits(fast_sums) != bits(exact_sums)).mean() < 0.02
+    # the option is really off again
+    assert np.array_equal(bits(renderer.render_sums(s.params, 0, 4)), bits(exact_sums))

@@ -41,7 +41,9 @@ for k in sorted(tot, key=lambda k: -tot[k].get("GRBM_GUI_ACTIVE", 0)):
     lanes = t["SQ_THREAD_CYCLES_VALU"] / t["SQ_ACTIVE_INST_VALU"] if t["SQ_ACTIVE_INST_VALU"] else 0.0
     occ = 4.0 * t["SQ_WAVE_CYCLES"] / simd_cycles if simd_cycles else 0.0
     hit = t["TCC_HIT_sum"] / (t["TCC_HIT_sum"] + t["TCC_MISS_sum"]) if t["TCC_HIT_sum"] + t["TCC_MISS_sum"] else 0.0
-    conflicts = t["SQ_LDS_BANK_CONFLICT"] / t["SQ_ACTIVE_INST_LDS"] if t["SQ_ACTIVE_INST_LDS"] else 0.0
+    # share of the LDS array's busy cycles that conflicts added (both count LDS-array cycles; dividing by
+    # SQ_ACTIVE_INST_LDS, which counts quad-cycles of instruction issue, gave figures above 100 %)
+    conflicts = t["SQ_LDS_BANK_CONFLICT"] / t["SQ_LDS_IDX_ACTIVE"] if t.get("SQ_LDS_IDX_ACTIVE") else 0.0
     print(f"| `{k}` | {n} | {100 * busy:.0f} % | {lanes:.1f} | {occ:.1f} | {100 * hit:.0f} % | "
           f"{t['FETCH_SIZE'] * 1024 / n / 1e6:.1f} MB | {t['WRITE_SIZE'] * 1024 / n / 1e6:.1f} MB | "
           f"{t['SQ_INSTS_VALU'] / n / 1e6:.1f} M | {100 * conflicts:.0f} % |")
