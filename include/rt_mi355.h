@@ -248,9 +248,15 @@ typedef void (*RtProgressFn)(uint32_t samples_done, void* user);
 uint32_t rt_abi_version(void);
 
 /* Create a context on GPU `device_ordinal`.  Fails with RT_ERR_NO_DEVICE when
- * there is none: there is no CPU fallback behind this library. */
+ * there is none: there is no CPU fallback behind this library.  Fails with
+ * RT_ERR_HIP when two HIP runtimes are mapped in the process (this library's and
+ * another package's private copy): rt_last_error(NULL) then names both.  One
+ * context drives one GPU; a host that renders on several GPUs creates one
+ * context per GPU (one thread or process each) and adds the radiance sums of
+ * rt_render_sums itself or with a collective. */
 int rt_create(int device_ordinal, RtContext** out);
 void rt_destroy(RtContext* ctx);
+/* Message of the last failure on `ctx`; with NULL, of this thread's last failed rt_create. */
 const char* rt_last_error(const RtContext* ctx);
 
 int rt_set_option(RtContext* ctx, uint32_t option, uint64_t value);

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RT_MI355_LIB_DIR points at another build of the two libraries (A/B timing of kernel variants).
@@ -170,6 +171,31 @@ def host_lib() -> C.CDLL:
     return _host
 
 
+def _map_torch_hip_runtime_first() -> None:
+    """One HIP runtime per process, whatever the import order.
+
+    PyTorch ships its own libamdhip64.so and asks the loader for it under that file
+    name; librt_mi355.so asks for the runtime under its soname, libamdhip64.so.7.
+    If ROCm's copy is mapped first (ours loaded before torch), the loader does not
+    recognise it under torch's name and maps torch's copy as well: two runtimes,
+    each with its own idea of devices, streams and allocations, and a pointer
+    handed from one to the other is invalid.  Mapping torch's copy first makes both
+    requests resolve to it (ours matches its soname).  torch itself is not imported."""
+    import importlib.util
+
+    if "torch" in sys.modules:
+        return  # its runtime is mapped already
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return  # no torch in this environment: ROCm's runtime is the only one
+    runtime = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(runtime):
+        C.CDLL(runtime, mode=C.RTLD_GLOBAL)
+
+
 def device_lib() -> C.CDLL:
     """librt_mi355.so (the HIP render loop).  Raises if it has not been built;
     nothing in this package renders without it."""
@@ -179,6 +205,7 @@ def device_lib() -> C.CDLL:
         if not os.path.exists(path):
             raise RuntimeError(f"{path} is missing: run `make -C raytracer_amd/csrc` "
                                "(or __graft_entry__.build()) first; there is no CPU fallback")
+        _map_torch_hip_runtime_first()
         _device = _bind(C.CDLL(path), _DEVICE_SYMBOLS)
         if _device.rt_abi_version() != RT_ABI_VERSION:
             raise RuntimeError("librt_mi355.so ABI version mismatch")

@@ -1,6 +1,7 @@
 // C ABI of librt_mi355.so (include/rt_mi355.h): context, scene upload with the
 // device re-layout, and the host-side driver of the wavefront bounce loop.
 #include <hip/hip_runtime.h>
+#include <link.h>
 
 #include <algorithm>
 #include <chrono>
@@ -870,9 +871,51 @@ extern "C" {
 
 uint32_t rt_abi_version(void) { return RT_ABI_VERSION; }
 
+// Message of the last failed rt_create of this thread (there is no context to hold it).
+static thread_local char g_create_error[512] = "";
+
+// Number of HIP runtimes mapped into this process, their paths in `paths`.
+static int count_hip_runtimes(char* paths, size_t cap) {
+    struct Found {
+        int n;
+        char* paths;
+        size_t cap;
+    } found{0, paths, cap};
+    paths[0] = 0;
+    dl_iterate_phdr(
+        [](struct dl_phdr_info* info, size_t, void* data) -> int {
+            Found* f = static_cast<Found*>(data);
+            const char* name = info->dlpi_name ? info->dlpi_name : "";
+            const char* base = std::strrchr(name, '/');
+            base = base ? base + 1 : name;
+            if (std::strncmp(base, "libamdhip64.so", 14) == 0) {
+                ++f->n;
+                const size_t used = std::strlen(f->paths);
+                std::snprintf(f->paths + used, f->cap - used, "%s%s", used ? ", " : "", name);
+            }
+            return 0;
+        },
+        &found);
+    return found.n;
+}
+
 int rt_create(int device_ordinal, RtContext** out) {
     if (!out) return RT_ERR_INVALID;
     *out = nullptr;
+    g_create_error[0] = 0;
+    {
+        // Two HIP runtimes in one process (typically ROCm's, which this library is linked against,
+        // and the copy a Python package such as PyTorch brings) do not share devices, streams or
+        // allocations: a device pointer or stream of one is garbage to the other.  Refuse to start.
+        char paths[400];
+        if (count_hip_runtimes(paths, sizeof paths) > 1) {
+            std::snprintf(g_create_error, sizeof g_create_error,
+                          "two HIP runtimes are mapped in this process (%s): load the one the process's other GPU "
+                          "code uses before librt_mi355.so (in Python: import torch first, or load the library "
+                          "through raytracer_amd._ffi, which does this)", paths);
+            return RT_ERR_HIP;
+        }
+    }
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return RT_ERR_NO_DEVICE;
     if (device_ordinal < 0 || device_ordinal >= n) return RT_ERR_NO_DEVICE;
@@ -925,7 +968,10 @@ void rt_destroy(RtContext* ctx) {
     delete ctx;
 }
 
-const char* rt_last_error(const RtContext* ctx) { return ctx ? ctx->error.c_str() : "null context"; }
+const char* rt_last_error(const RtContext* ctx) {
+    if (ctx) return ctx->error.c_str();
+    return g_create_error[0] ? g_create_error : "null context";
+}
 
 int rt_set_option(RtContext* ctx, uint32_t option, uint64_t value) {
     if (!ctx) return RT_ERR_INVALID;

@@ -89,7 +89,18 @@ def render_pass_exact(backend, sample_begin: int, sample_count: int, world: int,
 
 class GpuSumsBackend:
     """SumsBackend over librt_mi355.so: the library writes straight into a
-    torch CUDA tensor through its device pointer."""
+    torch CUDA tensor through its device pointer.
+
+    Ordering contract.  The library works on a stream of its own and returns from
+    every call only after that stream has drained, so torch (and RCCL) may use the
+    buffer right after a method here returns.  The other direction is the caller's
+    duty: torch.distributed's NCCL operations return once they are *enqueued*, so
+    `reduce_to_root`, `send` and `recv` passed to render_pass / render_pass_exact
+    must not return before the transfer has completed on the device (finish them
+    with torch.cuda.synchronize(), or wait on the work handle and synchronise the
+    stream), or the library's next call may read or overwrite data in flight.
+    `settle()` does that synchronisation; fold() and render_sums() call it first, so
+    a bare dist.recv / dist.reduce as callback is safe with this backend."""
 
     def __init__(self, renderer, params, device):
         import torch
@@ -99,16 +110,24 @@ class GpuSumsBackend:
         h, w = params.tile_shape()
         self.buffer = torch.empty(h * w * 3, dtype=torch.float32, device=device)
 
+    def settle(self) -> None:
+        """Wait for everything torch and RCCL have enqueued on this device."""
+        self._torch.cuda.synchronize(self.buffer.device)
+
     def render_sums(self, sample_begin: int, sample_count: int):
+        self.settle()  # an earlier collective may still be reading the buffer
         self.renderer.render_sums_device(self.params, sample_begin, sample_count, self.buffer.data_ptr())
         return self.buffer
 
     def zeros(self):
-        return self.buffer.zero_()
+        self.buffer.zero_()
+        self.settle()
+        return self.buffer
 
     def trace(self, sample_begin: int, sample_count: int) -> int:
         return self.renderer.trace_samples(self.params, sample_begin, sample_count)
 
     def fold(self, carry_on: bool):
+        self.settle()  # a receive into the buffer must have landed before it is folded onto
         self.renderer.fold_samples(self.params, carry_on, self.buffer.data_ptr(), sums_on_device=True)
         return self.buffer

@@ -238,10 +238,14 @@ def _render_passes(backend, image, params, grid, mine, copier, chunk, n_passes, 
 class GpuTileBackend:
     """TileBackend over librt_mi355.so.  Radiance sums stay on the GPU: the
     library writes them into a torch CUDA tensor (what RCCL reduces) through its
-    raw device pointer.  A process that uses torch on the GPU as well (groups of
-    several ranks) must `import torch` before the first Renderer is created:
-    torch ships its own HIP runtime, and whichever runtime is loaded first serves
-    both; torch does not find the GPU through the system's."""
+    raw device pointer.  (raytracer_amd._ffi maps torch's own HIP runtime before the
+    library, so both use one runtime whatever the import order.)
+
+    Ordering: the library returns from every call with its own stream drained, so
+    torch may use the tensor at once; in the other direction render_sums, fold and
+    zeros first wait for whatever torch / RCCL have enqueued on the device
+    (`settle`), so callbacks that are bare dist.reduce / dist.send / dist.recv
+    (which return once enqueued) are safe with this backend."""
 
     def __init__(self, renderer, device=None):
         self.renderer = renderer
@@ -262,13 +266,21 @@ class GpuTileBackend:
             self._buffer = torch.empty(n, dtype=torch.float32, device=self.device)
         return self._buffer[:n]
 
+    def settle(self):
+        import torch
+
+        torch.cuda.synchronize(self.device)
+
     def render_sums(self, params, sample_begin, sample_count):
         t = self._tensor(params)
+        self.settle()
         self.renderer.render_sums_device(params, sample_begin, sample_count, t.data_ptr())
         return t
 
     def zeros(self, params):
-        return self._tensor(params).zero_()
+        t = self._tensor(params).zero_()
+        self.settle()
+        return t
 
     def sums(self, params):
         return self._tensor(params)
@@ -278,6 +290,7 @@ class GpuTileBackend:
 
     def fold(self, params, carry_on):
         t = self._tensor(params)
+        self.settle()
         self.renderer.fold_samples(params, carry_on, t.data_ptr(), sums_on_device=True)
         return t
 

@@ -2,7 +2,6 @@ import os
 import sys
 
 import pytest
-import torch  # noqa: F401  -- before librt_mi355.so: a process that uses both must load torch's HIP runtime first
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
