@@ -43,6 +43,18 @@ pub struct RtRenderParams {
 #[repr(C)]
 pub struct RtContext { _private: [u8; 0] }
 
+#[repr(C)]
+pub struct RtHitRecord { pub t: f32, pub kind: u32, pub prim: u32 }
+#[repr(C)]
+pub struct RtStats {
+    pub paths: u64, pub segments: u64, pub hits: u64, pub branch_visits: u64, pub prim_tests: [u64; 3],
+    pub trace_launches: u64, pub trace_ms: f64, pub render_ms: f64,
+}
+// RtOption (the tuning knobs 4..14 never change results and are left to the C header)
+pub const RT_OPT_COUNT_TRAVERSAL: u32 = 1;
+pub const RT_OPT_TIME_KERNELS: u32 = 2;
+pub const RT_OPT_SAMPLES_IN_FLIGHT: u32 = 3;
+pub const RT_OPT_FAST_SLAB: u32 = 15; // not bit-exact when set
 pub const RT_LEAF_BIT: u32 = 0x8000_0000;
 pub const RT_NO_INDEX: u32 = 0xFFFF_FFFF;
 pub const RT_RNG_SEED: u64 = 0x0ef6_f79e_d30b_a75a; // src/rng.rs:10
@@ -86,6 +98,25 @@ unsafe extern "C" {
         ctx: *mut RtContext, shapes: *mut RtSphere, n: u32, nodes: *mut *mut RtNode, n_nodes: *mut u32,
     ) -> c_int;
     pub fn rt_free(p: *mut c_void);
+    pub fn rt_abi_version() -> u32;
+    pub fn rt_set_option(ctx: *mut RtContext, option: u32, value: u64) -> c_int;
+    pub fn rt_render_sums(
+        ctx: *mut RtContext, params: *const RtRenderParams, sample_begin: u32, sample_count: u32,
+        sums: *mut f32, sums_on_device: c_int,
+    ) -> c_int;
+    pub fn rt_trace_primary(
+        ctx: *mut RtContext, params: *const RtRenderParams, sample_index: u32, jitter: c_int, out: *mut RtHitRecord,
+    ) -> c_int;
+    pub fn rt_trace_rays(
+        ctx: *mut RtContext, origins: *const f32, directions: *const f32, n_rays: u64, out: *mut RtHitRecord,
+    ) -> c_int;
+    pub fn rt_trace_rays_noalloc(
+        ctx: *mut RtContext, origins: *const f32, directions: *const f32, n_rays: u64, out: *mut RtHitRecord,
+        on_device: c_int,
+    ) -> c_int;
+    pub fn rt_self_test(ctx: *mut RtContext, which: u32, n_cases: u64, failures: *mut u64) -> c_int;
+    pub fn rt_get_stats(ctx: *mut RtContext, out: *mut RtStats) -> c_int;
+    pub fn rt_reset_stats(ctx: *mut RtContext) -> c_int;
 }
 
 /// What `Scene::render` (src/lib.rs:188) becomes: flatten, upload, render into

@@ -87,3 +87,15 @@ def test_product_package_never_touches_the_oracle():
             if f.endswith((".py", ".cpp", ".h", ".hip", "Makefile")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in text.lower(), os.path.join(dirpath, f)
+
+
+def test_every_declared_entry_point_is_bound_in_python_and_in_the_rust_binding():
+    import re
+
+    header = open(os.path.join(ROOT, "include", "rt_mi355.h")).read()
+    declared = set(re.findall(r"^(?:int|void|uint32_t|const char\*)\s+(rt_\w+)\(", header, flags=re.M))
+    assert {"rt_create", "rt_render", "rt_trace_rays_noalloc", "rt_get_stats"} <= declared
+    assert declared == set(F._DEVICE_SYMBOLS)
+    rust = open(os.path.join(ROOT, "bindings", "rt_mi355.rs")).read()
+    bound = set(re.findall(r"pub fn (rt_\w+)\(", rust))
+    assert declared <= bound, sorted(declared - bound)
