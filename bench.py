@@ -200,6 +200,8 @@ def main() -> None:
     ap.add_argument("--trace-waves-per-cu", type=int, default=0, help="cap on resident traversal waves per CU (0 = automatic)")
     ap.add_argument("--shade-groups", type=int, default=None, help="shading workgroups per CU (library default: 8)")
     ap.add_argument("--chains", type=int, default=None, help="independent chains a batch is split into (library default: 2)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="library tuning option by the name of its RT_OPT_ constant, e.g. TRACE_REFILL_MIN=8 (repeatable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fast", action="store_true",
                     help="RT_OPT_FAST_SLAB: reciprocal-direction slab test with fused multiply-add (not bit-exact; the line "
@@ -255,6 +257,9 @@ def main() -> None:
     r.set_option(F.RT_OPT_TRACE_WAVES_PER_CU, args.trace_waves_per_cu)
     if args.shade_groups is not None:
         r.set_option(F.RT_OPT_SHADE_GROUPS_PER_CU, args.shade_groups)
+    for kv in args.opt:
+        name, value = kv.split("=")
+        r.set_option(getattr(F, "RT_OPT_" + name), int(value))
     params = scene.params
     tiled = args.workload == "room16k"
     count_params = params

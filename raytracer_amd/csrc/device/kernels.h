@@ -332,7 +332,7 @@ struct TraceArgs {
     uint32_t refill_min;     // idle lanes that trigger a refill from the queue (1..64)
     int bounds_fast;         // every box coordinate is 0 or has magnitude in [2^-60, 2^59)
     unsigned long long* counters;  // [0] branch visits, [1] shape tests (COUNT only)
-    unsigned long long* wave_tallies;  // six diagnostic words, triangle family only (COUNT only)
+    unsigned long long* wave_tallies;  // six diagnostic words, then 32 of branch visits by depth band; triangle family only (COUNT only)
 };
 
 // A workgroup is WAVES independent waves that share one thing: a copy in LDS of
@@ -568,7 +568,11 @@ __global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num
                 }
                 h0 = h0 && d0 < best_t;  // bvh.rs:263-266
                 h1 = h1 && d1 < best_t;
-                if (COUNT) ++n_branch;
+                if (COUNT) {
+                    ++n_branch;
+                    // diagnostic: visits by depth band of the breadth-first numbering (records 2^k - 1 .. 2^(k+1) - 2)
+                    if (a.wave_tallies) atomicAdd(&a.wave_tallies[6 + (31 - __clz(static_cast<int>(item + 1u)))], 1ull);
+                }
                 // bvh.rs:268-285.  With both children hit the farther one is pushed and
                 // the nearer kept in hand; on equal distances child 1 is the nearer.
                 const bool zero_near = d0 < d1;

@@ -130,12 +130,12 @@ struct RtContext {
     size_t events_used = 0;
 
     RtStats stats{};
-    unsigned long long tallies[6] = {};  // diagnostics: see k_trace
+    unsigned long long tallies[38] = {};  // diagnostics: see k_trace
 };
 
 namespace {
 
-constexpr size_t kStatWords = 15;  // + six diagnostic tallies of the triangle traversal
+constexpr size_t kStatWords = 47;  // + 38 diagnostic tallies of the triangle traversal
 
 int fail(RtContext* ctx, int code, const std::string& msg) {
     if (ctx) ctx->error = msg;
@@ -569,7 +569,7 @@ int harvest(RtContext* ctx) {
     }
     ctx->stats.prim_tests[0] += h[7];
     ctx->stats.prim_tests[1] += h[8];
-    for (int k = 0; k < 6; ++k) ctx->tallies[k] += h[9 + k];
+    for (int k = 0; k < 38; ++k) ctx->tallies[k] += h[9 + k];
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof h, ctx->stream));
     return RT_OK;
 }
@@ -1517,6 +1517,11 @@ int rt_reset_stats(RtContext* ctx) {
     if (std::getenv("RT_MI355_DEBUG_TALLIES"))
         std::fprintf(stderr, "[rt_mi355] iters %llu active_lanes %llu branch_runs %llu branch_lanes %llu shape_runs %llu shape_lanes %llu\n",
                      ctx->tallies[0], ctx->tallies[1], ctx->tallies[2], ctx->tallies[3], ctx->tallies[4], ctx->tallies[5]);
+    if (std::getenv("RT_MI355_DEBUG_TALLIES")) {
+        std::fprintf(stderr, "[rt_mi355] branch visits by depth band:");
+        for (int k = 0; k < 32; ++k) std::fprintf(stderr, " %llu", ctx->tallies[6 + k]);
+        std::fprintf(stderr, "\n");
+    }
     for (unsigned long long& t : ctx->tallies) t = 0;
     ctx->stats = RtStats{};
     return RT_OK;

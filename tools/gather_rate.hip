@@ -29,6 +29,24 @@ __global__ void __launch_bounds__(512) k_gather(const float4* table, uint32_t ma
         if (PATTERN == 0) {
             const float4 v = table[(r & mask_records) * 4u + (r >> 30)];
             acc += v.x + v.w;
+        } else if (PATTERN >= 6) {
+            // pattern 1 with a cache policy on the loads: 6 nt, 7 sc1, 8 sc0 sc1, 9 sc0 sc1 nt, 10 sc0
+            const float4* p = table + (r & mask_records) * 4u;
+            float4 a, b, c, d;
+#define RT_GATHER4(POLICY)                                                                                                 \
+    asm volatile("global_load_dwordx4 %0, %4, off " POLICY "\n\tglobal_load_dwordx4 %1, %4, off offset:16 " POLICY               \
+                 "\n\tglobal_load_dwordx4 %2, %4, off offset:32 " POLICY "\n\tglobal_load_dwordx4 %3, %4, off offset:48 " POLICY \
+                 "\n\ts_waitcnt vmcnt(0)"                                                                                  \
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d)                                                                  \
+                 : "v"(p)                                                                                                  \
+                 : "memory")
+            if (PATTERN == 6) RT_GATHER4("nt");
+            else if (PATTERN == 7) RT_GATHER4("sc1");
+            else if (PATTERN == 8) RT_GATHER4("sc0 sc1");
+            else if (PATTERN == 9) RT_GATHER4("sc0 sc1 nt");
+            else if (PATTERN == 10) RT_GATHER4("sc0");
+            else RT_GATHER4("");
+            acc += a.x + b.y + c.z + d.w;
         } else if (PATTERN == 1) {
             const float4* p = table + (r & mask_records) * 4u;
             const float4 a = p[0], b = p[1], c = p[2], d = p[3];
@@ -97,6 +115,12 @@ int main() {
         run<3>("  runs of 5 lanes, 48-B records (3 loads)", table, records, 3, n_cus, ghz, out);
         run<4>("  runs of 5 lanes, 3 arrays of 16 B", table, records, 3, n_cus, ghz, out);
         run<5>("  runs of 5 lanes, 32 B (2 loads) + 4 B", table, records, 3, n_cus, ghz, out);
+        run<11>("  four quarters, asm, default policy", table, records, 4, n_cus, ghz, out);
+        run<6>("  four quarters, nt", table, records, 4, n_cus, ghz, out);
+        run<10>("  four quarters, sc0", table, records, 4, n_cus, ghz, out);
+        run<7>("  four quarters, sc1", table, records, 4, n_cus, ghz, out);
+        run<8>("  four quarters, sc0 sc1", table, records, 4, n_cus, ghz, out);
+        run<9>("  four quarters, sc0 sc1 nt", table, records, 4, n_cus, ghz, out);
         hipFree(table);
     }
     return 0;
