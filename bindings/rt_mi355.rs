@@ -42,6 +42,8 @@ pub struct RtRenderParams {
 }
 #[repr(C)]
 pub struct RtContext { _private: [u8; 0] }
+#[repr(C)]
+pub struct RtGroup { _private: [u8; 0] }
 
 #[repr(C)]
 pub struct RtHitRecord { pub t: f32, pub kind: u32, pub prim: u32 }
@@ -117,6 +119,23 @@ unsafe extern "C" {
     pub fn rt_self_test(ctx: *mut RtContext, which: u32, n_cases: u64, failures: *mut u64) -> c_int;
     pub fn rt_get_stats(ctx: *mut RtContext, out: *mut RtStats) -> c_int;
     pub fn rt_reset_stats(ctx: *mut RtContext) -> c_int;
+    // Several GPUs behind one handle: `Scene::render` over a list of GPUs, same bytes as one GPU.
+    pub fn rt_group_create(device_ordinals: *const c_int, n_devices: u32, out: *mut *mut RtGroup) -> c_int;
+    pub fn rt_group_destroy(group: *mut RtGroup);
+    pub fn rt_group_last_error(group: *const RtGroup) -> *const c_char;
+    pub fn rt_group_size(group: *const RtGroup) -> u32;
+    pub fn rt_group_member(group: *mut RtGroup, index: u32) -> *mut RtContext;
+    pub fn rt_group_set_option(group: *mut RtGroup, option: u32, value: u64) -> c_int;
+    pub fn rt_group_upload_scene(group: *mut RtGroup, scene: *const RtSceneDesc) -> c_int;
+    pub fn rt_group_render(
+        group: *mut RtGroup, params: *const RtRenderParams, rgb8: *mut u8,
+        progress: Option<unsafe extern "C" fn(u32, *mut c_void)>, user: *mut c_void,
+    ) -> c_int;
+    pub fn rt_group_render_sums(
+        group: *mut RtGroup, params: *const RtRenderParams, sample_begin: u32, sample_count: u32, sums: *mut f32,
+    ) -> c_int;
+    pub fn rt_group_get_stats(group: *mut RtGroup, out: *mut RtStats) -> c_int;
+    pub fn rt_group_reset_stats(group: *mut RtGroup) -> c_int;
 }
 
 /// What `Scene::render` (src/lib.rs:188) becomes: flatten, upload, render into

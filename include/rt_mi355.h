@@ -375,6 +375,41 @@ int rt_self_test(RtContext* ctx, uint32_t which, uint64_t n_cases, uint64_t* fai
 int rt_get_stats(RtContext* ctx, RtStats* out);
 int rt_reset_stats(RtContext* ctx);
 
+/* ---- several GPUs of one node behind one handle ------------------------------
+ *
+ * The reference's seam is one `Scene::render(&self)` call
+ * (/root/reference/src/lib.rs:188-301) whose threads share the pixels of a frame
+ * (:195-235).  A group is that call over a list of GPUs: the scene is replicated,
+ * a pass's samples are split into contiguous shares that the GPUs trace at the
+ * same time (one host thread per GPU inside the library), and the per-pixel sums
+ * then travel from GPU to GPU in sample order, each folding its samples onto
+ * them.  The fold of :274-279 is therefore the same sequence of additions as on
+ * one GPU: rt_group_render stores the bytes rt_render stores, and
+ * rt_group_render_sums returns the floats rt_render_sums returns, whatever the
+ * number of GPUs (a GPU may be listed more than once).  The calls of one group
+ * must not overlap in time. */
+typedef struct RtGroup RtGroup;
+/* One context per listed ordinal (rt_create's conditions apply to each). */
+int rt_group_create(const int* device_ordinals, uint32_t n_devices, RtGroup** out);
+void rt_group_destroy(RtGroup* group);
+/* Message of the last failure on `group`; with NULL, of this thread's last failed rt_group_create. */
+const char* rt_group_last_error(const RtGroup* group);
+uint32_t rt_group_size(const RtGroup* group);
+/* The context of member `index` (owned by the group), e.g. for rt_trace_primary; NULL beyond the end. */
+RtContext* rt_group_member(RtGroup* group, uint32_t index);
+/* rt_set_option / rt_upload_scene on every member (uploads run side by side). */
+int rt_group_set_option(RtGroup* group, uint32_t option, uint64_t value);
+int rt_group_upload_scene(RtGroup* group, const RtSceneDesc* scene);
+/* rt_render over the group: same arguments, same bytes. */
+int rt_group_render(RtGroup* group, const RtRenderParams* params, uint8_t* rgb8,
+                    RtProgressFn progress, void* user);
+/* rt_render_sums over the group (`sums` is host memory): same floats. */
+int rt_group_render_sums(RtGroup* group, const RtRenderParams* params,
+                         uint32_t sample_begin, uint32_t sample_count, float* sums);
+/* Counters summed over the members; render_ms is the largest member's. */
+int rt_group_get_stats(RtGroup* group, RtStats* out);
+int rt_group_reset_stats(RtGroup* group);
+
 #ifdef __cplusplus
 }
 #endif

@@ -122,6 +122,17 @@ _DEVICE_SYMBOLS = {
     "rt_self_test": (C.c_int, [C.c_void_p, u32, u64, C.POINTER(u64)]),
     "rt_get_stats": (C.c_int, [C.c_void_p, C.POINTER(RtStats)]),
     "rt_reset_stats": (C.c_int, [C.c_void_p]),
+    "rt_group_create": (C.c_int, [C.POINTER(C.c_int), u32, C.POINTER(C.c_void_p)]),
+    "rt_group_destroy": (None, [C.c_void_p]),
+    "rt_group_last_error": (C.c_char_p, [C.c_void_p]),
+    "rt_group_size": (u32, [C.c_void_p]),
+    "rt_group_member": (C.c_void_p, [C.c_void_p, u32]),
+    "rt_group_set_option": (C.c_int, [C.c_void_p, u32, u64]),
+    "rt_group_upload_scene": (C.c_int, [C.c_void_p, C.POINTER(RtSceneDesc)]),
+    "rt_group_render": (C.c_int, [C.c_void_p, C.POINTER(RtRenderParams), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rt_group_render_sums": (C.c_int, [C.c_void_p, C.POINTER(RtRenderParams), u32, u32, C.c_void_p]),
+    "rt_group_get_stats": (C.c_int, [C.c_void_p, C.POINTER(RtStats)]),
+    "rt_group_reset_stats": (C.c_int, [C.c_void_p]),
 }
 
 RthTriangleBvhFn = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_void_p, u32, C.POINTER(u32))

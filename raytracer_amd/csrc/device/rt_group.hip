@@ -1,0 +1,289 @@
+// Several GPUs of one node behind one handle: the rt_group_* entry points of
+// rt_mi355.h.  The reference's seam is a single `Scene::render(&self)` call
+// (/root/reference/src/lib.rs:188); a host that hands that call to this library
+// with a list of GPUs gets the image one GPU would store, bit for bit.
+//
+// The scene is replicated (one context per listed GPU).  A pass's samples are
+// split into contiguous shares, every member traces its share at the same time
+// on a host thread of its own (rt_trace_samples: per-sample radiance stays on
+// the member's GPU), then the running per-pixel sums travel from member to
+// member in sample order (hipMemcpyPeer) and each member folds its samples onto
+// them (rt_fold_samples): the left fold of lib.rs:274-279 is the same sequence
+// of additions whatever the number of members.  No collective is needed: the
+// path has no exchange step other than this hand-over of 12 bytes per pixel.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "rt_mi355.h"
+
+struct RtGroup {
+    std::vector<RtContext*> member;
+    std::vector<int> device;
+    std::vector<float*> d_sums;  // per member, on its GPU: 3 floats per pixel
+    size_t cap_pixels = 0;
+    std::vector<float> h_sums;   // the finished sums of a pass, for rt_resolve
+    std::string error;
+};
+
+namespace {
+
+thread_local char g_group_error[512] = "";
+
+int group_fail(RtGroup* g, int code, const std::string& msg) {
+    g->error = msg;
+    return code;
+}
+
+// A member's failure, with its message.
+int member_fail(RtGroup* g, size_t k, int code) {
+    g->error = "GPU " + std::to_string(g->device[k]) + " (member " + std::to_string(k) + "): " + rt_last_error(g->member[k]);
+    return code;
+}
+
+void free_sums(RtGroup* g) {
+    for (size_t k = 0; k < g->d_sums.size(); ++k) {
+        if (!g->d_sums[k]) continue;
+        (void)hipSetDevice(g->device[k]);
+        (void)hipFree(g->d_sums[k]);
+        g->d_sums[k] = nullptr;
+    }
+    g->cap_pixels = 0;
+}
+
+int ensure_sums(RtGroup* g, size_t n_pixels) {
+    if (g->cap_pixels >= n_pixels) return RT_OK;
+    free_sums(g);
+    for (size_t k = 0; k < g->member.size(); ++k) {
+        if (hipSetDevice(g->device[k]) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&g->d_sums[k]), n_pixels * 3 * sizeof(float)) != hipSuccess) {
+            (void)hipGetLastError();
+            free_sums(g);
+            return group_fail(g, RT_ERR_OOM, "no memory for the per-pixel sums on GPU " + std::to_string(g->device[k]));
+        }
+    }
+    g->cap_pixels = n_pixels;
+    return RT_OK;
+}
+
+size_t pixels_of(const RtRenderParams* p) {
+    return p->tile_w ? static_cast<size_t>(p->tile_w) * p->tile_h : static_cast<size_t>(p->width) * p->height;
+}
+
+// Member k's share of `count` samples: contiguous, earlier members take the larger shares.
+void share_of(uint32_t count, size_t n, size_t k, uint32_t* first, uint32_t* mine) {
+    const uint32_t base = count / static_cast<uint32_t>(n), extra = count % static_cast<uint32_t>(n);
+    *mine = base + (k < extra ? 1u : 0u);
+    *first = base * static_cast<uint32_t>(k) + static_cast<uint32_t>(std::min<size_t>(k, extra));
+}
+
+// Samples [begin, begin + count) of every pixel folded onto the sums of the samples before
+// them (`carry_on`: member 0's buffer holds those; otherwise the fold starts empty).  On
+// return the buffer of the last member that had samples holds the result; its index is
+// returned in *holder.
+int group_sums(RtGroup* g, const RtRenderParams* p, uint32_t begin, uint32_t count, bool carry_on, size_t* holder) {
+    const size_t n = g->member.size();
+    const size_t bytes = pixels_of(p) * 3 * sizeof(float);
+    std::vector<uint32_t> first(n), mine(n), traced(n, 0);
+    std::vector<int> rc(n, RT_OK);
+    for (size_t k = 0; k < n; ++k) share_of(count, n, k, &first[k], &mine[k]);
+    // every member traces (the first piece of) its share at the same time
+    {
+        std::vector<std::thread> workers;
+        for (size_t k = 1; k < n; ++k)
+            if (mine[k])
+                workers.emplace_back([&, k] { rc[k] = rt_trace_samples(g->member[k], p, begin + first[k], mine[k], &traced[k]); });
+        if (mine[0]) rc[0] = rt_trace_samples(g->member[0], p, begin + first[0], mine[0], &traced[0]);
+        for (std::thread& t : workers) t.join();
+    }
+    for (size_t k = 0; k < n; ++k)
+        if (rc[k] != RT_OK) return member_fail(g, k, rc[k]);
+    // the sums go from member to member in sample order
+    size_t last = 0;
+    bool have = carry_on;  // does some buffer hold the fold so far?
+    for (size_t k = 0; k < n; ++k) {
+        if (!mine[k]) continue;
+        if (have && k != last) {
+            if (hipMemcpyPeer(g->d_sums[k], g->device[k], g->d_sums[last], g->device[last], bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                return group_fail(g, RT_ERR_HIP, "copy of the sums between GPUs failed");
+            }
+        }
+        uint32_t done = 0;
+        while (done < mine[k]) {
+            if (done) {  // the share did not fit in flight at once: the rest, piece by piece
+                const int r = rt_trace_samples(g->member[k], p, begin + first[k] + done, mine[k] - done, &traced[k]);
+                if (r != RT_OK) return member_fail(g, k, r);
+            }
+            const int r = rt_fold_samples(g->member[k], p, have ? 1 : 0, g->d_sums[k], 1);
+            if (r != RT_OK) return member_fail(g, k, r);
+            have = true;
+            done += traced[k];
+        }
+        last = k;
+    }
+    *holder = last;
+    return RT_OK;
+}
+
+int check_group(RtGroup* g, const RtRenderParams* p) {
+    if (!g) return RT_ERR_INVALID;
+    if (!p) return group_fail(g, RT_ERR_INVALID, "null render parameters");
+    if (p->width < 2 || p->height < 2) return group_fail(g, RT_ERR_INVALID, "width and height must be at least 2");
+    return ensure_sums(g, pixels_of(p));
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_group_create(const int* device_ordinals, uint32_t n_devices, RtGroup** out) {
+    if (!out) return RT_ERR_INVALID;
+    *out = nullptr;
+    g_group_error[0] = 0;
+    if (!device_ordinals || n_devices == 0 || n_devices > 64) {
+        std::snprintf(g_group_error, sizeof g_group_error, "a group takes a list of 1..64 GPU ordinals");
+        return RT_ERR_INVALID;
+    }
+    RtGroup* g = new (std::nothrow) RtGroup;
+    if (!g) return RT_ERR_OOM;
+    for (uint32_t k = 0; k < n_devices; ++k) {
+        RtContext* ctx = nullptr;
+        const int rc = rt_create(device_ordinals[k], &ctx);
+        if (rc != RT_OK) {
+            std::snprintf(g_group_error, sizeof g_group_error, "GPU %d: %s", device_ordinals[k],
+                          rc == RT_ERR_NO_DEVICE ? "no such device" : rt_last_error(nullptr));
+            rt_group_destroy(g);
+            return rc;
+        }
+        g->member.push_back(ctx);
+        g->device.push_back(device_ordinals[k]);
+        g->d_sums.push_back(nullptr);
+    }
+    // direct copies between the members' GPUs where the hardware allows them (xGMI);
+    // hipMemcpyPeer goes through host memory otherwise
+    for (uint32_t a = 0; a < n_devices; ++a)
+        for (uint32_t b = 0; b < n_devices; ++b) {
+            int can = 0;
+            if (g->device[a] == g->device[b]) continue;
+            if (hipDeviceCanAccessPeer(&can, g->device[a], g->device[b]) == hipSuccess && can && hipSetDevice(g->device[a]) == hipSuccess)
+                (void)hipDeviceEnablePeerAccess(g->device[b], 0);  // "already enabled" is fine
+            (void)hipGetLastError();
+        }
+    *out = g;
+    return RT_OK;
+}
+
+void rt_group_destroy(RtGroup* g) {
+    if (!g) return;
+    free_sums(g);
+    for (RtContext* ctx : g->member) rt_destroy(ctx);
+    delete g;
+}
+
+const char* rt_group_last_error(const RtGroup* g) {
+    if (g) return g->error.c_str();
+    return g_group_error[0] ? g_group_error : "null group";
+}
+
+uint32_t rt_group_size(const RtGroup* g) { return g ? static_cast<uint32_t>(g->member.size()) : 0u; }
+
+RtContext* rt_group_member(RtGroup* g, uint32_t index) { return g && index < g->member.size() ? g->member[index] : nullptr; }
+
+int rt_group_set_option(RtGroup* g, uint32_t option, uint64_t value) {
+    if (!g) return RT_ERR_INVALID;
+    for (size_t k = 0; k < g->member.size(); ++k) {
+        const int rc = rt_set_option(g->member[k], option, value);
+        if (rc != RT_OK) return member_fail(g, k, rc);
+    }
+    return RT_OK;
+}
+
+int rt_group_upload_scene(RtGroup* g, const RtSceneDesc* scene) {
+    if (!g) return RT_ERR_INVALID;
+    const size_t n = g->member.size();
+    std::vector<int> rc(n, RT_OK);
+    std::vector<std::thread> workers;
+    for (size_t k = 1; k < n; ++k) workers.emplace_back([&, k] { rc[k] = rt_upload_scene(g->member[k], scene); });
+    rc[0] = rt_upload_scene(g->member[0], scene);
+    for (std::thread& t : workers) t.join();
+    for (size_t k = 0; k < n; ++k)
+        if (rc[k] != RT_OK) return member_fail(g, k, rc[k]);
+    return RT_OK;
+}
+
+int rt_group_render_sums(RtGroup* g, const RtRenderParams* p, uint32_t sample_begin, uint32_t sample_count, float* sums) {
+    int rc = check_group(g, p);
+    if (rc != RT_OK) return rc;
+    if (!sums || sample_count == 0) return group_fail(g, RT_ERR_INVALID, "bad arguments");
+    size_t holder = 0;
+    rc = group_sums(g, p, sample_begin, sample_count, false, &holder);
+    if (rc != RT_OK) return rc;
+    if (hipSetDevice(g->device[holder]) != hipSuccess ||
+        hipMemcpy(sums, g->d_sums[holder], pixels_of(p) * 3 * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return group_fail(g, RT_ERR_HIP, "copy of the sums to the host failed");
+    }
+    return RT_OK;
+}
+
+int rt_group_render(RtGroup* g, const RtRenderParams* p, uint8_t* rgb8, RtProgressFn progress, void* user) {
+    int rc = check_group(g, p);
+    if (rc != RT_OK) return rc;
+    if (!rgb8) return group_fail(g, RT_ERR_INVALID, "null pixel buffer");
+    // lib.rs:206-211
+    const uint32_t chunk = p->incremental ? p->incremental : p->samples_per_pixel;
+    if (chunk == 0 || p->samples_per_pixel % chunk != 0)
+        return group_fail(g, RT_ERR_INVALID, "incremental must be non-zero and divide the samples per pixel");
+    const uint32_t n_passes = p->samples_per_pixel / chunk;
+    const int running = p->incremental != 0 || p->has_continue != 0;  // lib.rs:286
+    const uint32_t first_pass = p->has_continue ? p->continue_sampling : 0;
+    const size_t n_values = pixels_of(p) * 3;
+    g->h_sums.resize(n_values);
+    for (uint32_t pass = 0; pass < n_passes; ++pass) {
+        const uint32_t k = pass + first_pass;  // sample_iteration, lib.rs:233-234
+        const uint64_t s_begin = static_cast<uint64_t>(k) * chunk;
+        if (s_begin + chunk > 0xFFFFFFFFull) return group_fail(g, RT_ERR_INVALID, "sample index overflow");
+        rc = rt_group_render_sums(g, p, static_cast<uint32_t>(s_begin), chunk, g->h_sums.data());
+        if (rc != RT_OK) return rc;
+        // mean, gamma, running average and quantisation (lib.rs:283-295) on the first member;
+        // the image is readable after every pass
+        rc = rt_resolve(g->member[0], p, g->h_sums.data(), 0, chunk, running, k, rgb8);
+        if (rc != RT_OK) return member_fail(g, 0, rc);
+        if (progress) progress(first_pass + (pass + 1) * chunk, user);  // lib.rs:238-246
+    }
+    return RT_OK;
+}
+
+int rt_group_get_stats(RtGroup* g, RtStats* out) {
+    if (!g || !out) return RT_ERR_INVALID;
+    RtStats total{};
+    for (size_t k = 0; k < g->member.size(); ++k) {
+        RtStats s{};
+        const int rc = rt_get_stats(g->member[k], &s);
+        if (rc != RT_OK) return member_fail(g, k, rc);
+        total.paths += s.paths;
+        total.segments += s.segments;
+        total.hits += s.hits;
+        total.branch_visits += s.branch_visits;
+        for (int f = 0; f < 3; ++f) total.prim_tests[f] += s.prim_tests[f];
+        total.trace_launches += s.trace_launches;
+        total.trace_ms += s.trace_ms;
+        total.render_ms = std::max(total.render_ms, s.render_ms);  // members work side by side
+    }
+    *out = total;
+    return RT_OK;
+}
+
+int rt_group_reset_stats(RtGroup* g) {
+    if (!g) return RT_ERR_INVALID;
+    for (RtContext* ctx : g->member) (void)rt_reset_stats(ctx);
+    return RT_OK;
+}
+
+}  // extern "C"

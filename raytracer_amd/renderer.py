@@ -212,3 +212,79 @@ class Renderer:
 
     def reset_stats(self) -> None:
         self._check(self._lib.rt_reset_stats(self._ctx))
+
+
+class RendererGroup:
+    """Several GPUs of one node behind one handle (rt_group_* of include/rt_mi355.h):
+    `Scene::render` over a list of GPUs, storing the bytes one GPU stores."""
+
+    def __init__(self, devices):
+        self._lib = F.device_lib()
+        self._group = C.c_void_p()
+        devices = [int(d) for d in devices]
+        arr = (C.c_int * len(devices))(*devices)
+        rc = self._lib.rt_group_create(arr, len(devices), C.byref(self._group))
+        if rc != 0:
+            self._group = C.c_void_p()
+            raise RtError(rc, self._lib.rt_group_last_error(None).decode())
+        self._scene = None
+
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            raise RtError(rc, self._lib.rt_group_last_error(self._group).decode())
+
+    def close(self) -> None:
+        if self._group:
+            self._lib.rt_group_destroy(self._group)
+            self._group = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self) -> int:
+        return int(self._lib.rt_group_size(self._group))
+
+    def set_option(self, option: int, value: int) -> None:
+        self._check(self._lib.rt_group_set_option(self._group, option, value))
+
+    def upload(self, scene: Scene) -> None:
+        d = scene.desc()
+        self._check(self._lib.rt_group_upload_scene(self._group, C.byref(d)))
+        self._scene = scene
+
+    def render(self, params, rgb8: np.ndarray | None = None, progress=None) -> np.ndarray:
+        h, w = params.tile_shape()
+        if rgb8 is None:
+            rgb8 = np.zeros((h, w, 3), dtype=np.uint8)
+        assert rgb8.dtype == np.uint8 and rgb8.shape == (h, w, 3) and rgb8.flags.c_contiguous
+        cb = F.RtProgressFn(lambda done, _user: progress(int(done))) if progress else None
+        self._check(self._lib.rt_group_render(self._group, C.byref(params), rgb8.ctypes.data,
+                                              C.cast(cb, C.c_void_p) if cb else None, None))
+        return rgb8
+
+    def render_sums(self, params, sample_begin: int, sample_count: int) -> np.ndarray:
+        h, w = params.tile_shape()
+        out = np.empty((h, w, 3), dtype=np.float32)
+        self._check(self._lib.rt_group_render_sums(self._group, C.byref(params), sample_begin, sample_count,
+                                                   out.ctypes.data))
+        return out
+
+    def stats(self) -> dict:
+        s = F.RtStats()
+        self._check(self._lib.rt_group_get_stats(self._group, C.byref(s)))
+        return {"paths": int(s.paths), "segments": int(s.segments), "hits": int(s.hits),
+                "branch_visits": int(s.branch_visits), "prim_tests": [int(v) for v in s.prim_tests],
+                "trace_launches": int(s.trace_launches), "trace_ms": float(s.trace_ms),
+                "render_ms": float(s.render_ms)}
+
+    def reset_stats(self) -> None:
+        self._check(self._lib.rt_group_reset_stats(self._group))

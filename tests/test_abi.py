@@ -93,8 +93,8 @@ def test_every_declared_entry_point_is_bound_in_python_and_in_the_rust_binding()
     import re
 
     header = open(os.path.join(ROOT, "include", "rt_mi355.h")).read()
-    declared = set(re.findall(r"^(?:int|void|uint32_t|const char\*)\s+(rt_\w+)\(", header, flags=re.M))
-    assert {"rt_create", "rt_render", "rt_trace_rays_noalloc", "rt_get_stats"} <= declared
+    declared = set(re.findall(r"^(?:int|void|uint32_t|const char\*|RtContext\*)\s+(rt_\w+)\(", header, flags=re.M))
+    assert {"rt_create", "rt_render", "rt_trace_rays_noalloc", "rt_get_stats", "rt_group_render", "rt_group_member"} <= declared
     assert declared == set(F._DEVICE_SYMBOLS)
     rust = open(os.path.join(ROOT, "bindings", "rt_mi355.rs")).read()
     bound = set(re.findall(r"pub fn (rt_\w+)\(", rust))

@@ -1,0 +1,58 @@
+"""Several GPUs behind one handle (rt_group_*): the image and the radiance sums of a group
+are the single-GPU ones, bit for bit, whatever the number of members.  On a one-GPU box the
+members are several contexts on GPU 0 (a GPU may be listed more than once), which runs the
+same code: member threads, the hand-over of the sums from member to member, the fold order."""
+import numpy as np
+import pytest
+
+from oracle import binding as O
+from raytracer_amd import _ffi as F
+from raytracer_amd.renderer import RendererGroup, RtError
+
+from . import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("members", [1, 2, 3])
+def test_group_sums_and_bytes_equal_the_oracle(members, asset_root):
+    s = scenes.room(asset_root, w=64, h=36, spp=7, bounces=12)  # 7 samples: uneven shares (3, 2, 2)
+    with RendererGroup([0] * members) as g:
+        assert len(g) == members
+        g.upload(s)
+        sums = g.render_sums(s.params, 0, 7)
+        assert np.array_equal(bits(sums), bits(O.render_sums(s, s.params, 0, 7, threads=4)))
+        assert np.array_equal(g.render(s.params), O.render(s, s.params, threads=4)[0])
+        st = g.stats()
+        assert st["paths"] == 2 * 64 * 36 * 7
+
+
+def test_group_equals_one_context_with_pieces_and_incremental(renderer, asset_root):
+    s = scenes.room(asset_root, w=48, h=32, spp=12, bounces=10, incremental=4)
+    renderer.upload(s)
+    seen = []
+    one = renderer.render(s.params, progress=seen.append)
+    with RendererGroup([0, 0]) as g:
+        g.upload(s)
+        g.set_option(F.RT_OPT_SAMPLES_IN_FLIGHT, 1)  # a member's share of 2 samples does not fit at once
+        got = []
+        two = g.render(s.params, progress=got.append)
+        assert got == seen == [4, 8, 12]
+        assert np.array_equal(one, two)
+        # fewer samples than members: the later members have nothing to do
+        assert np.array_equal(bits(g.render_sums(s.params, 5, 1)), bits(renderer.render_sums(s.params, 5, 1)))
+
+
+def test_group_errors():
+    with pytest.raises(RtError):
+        RendererGroup([])
+    with pytest.raises(RtError):
+        RendererGroup([0, 4096])  # no such GPU
+    s = scenes.sphere_plane(w=16, h=8, spp=2)
+    with RendererGroup([0]) as g:
+        with pytest.raises(RtError):
+            g.render_sums(s.params, 0, 2)  # no scene uploaded

@@ -14,7 +14,7 @@ fi
 cd "$SRC/raytracer_amd/csrc"
 /opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math \
   -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-flush-denormals-to-zero -fno-slp-vectorize \
-  -I"$SRC/include" "$@" -shared -o "$OUT/librt_mi355.so" device/rt_context.hip device/bvh_build.hip
+  -I"$SRC/include" "$@" -shared -o "$OUT/librt_mi355.so" device/rt_context.hip device/bvh_build.hip device/rt_group.hip
 cp "$ROOT/raytracer_amd/lib/librt_host.so" "$OUT/"
 [ "$REV" != "." ] && rm -rf "$SRC"
 echo "built $OUT"
