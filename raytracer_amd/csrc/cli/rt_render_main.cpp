@@ -2,7 +2,12 @@
 // (/root/reference/src/main.rs:5-8): read the file `scene` from the working
 // directory, parse it, render into the memory-mapped `target/out.ppm`.
 //
-//   rt_render [scene-file [output.ppm [gpu-ordinal [tile-edge [accumulator-file]]]]]
+//   rt_render [scene-file [output.ppm [gpu-ordinals [tile-edge [accumulator-file]]]]]
+//
+// gpu-ordinals is one ordinal or a comma-separated list ("0,1,2,3"): with a list
+// the GPUs share every pass's samples (rt_group_render) and the image is the one
+// a single GPU stores, byte for byte.  The accumulator-file mode runs on the
+// first GPU of the list.
 //
 // `obj/<name>.obj` paths in the scene file are resolved against the working
 // directory, as in the reference.  The output file is never truncated, so a
@@ -105,7 +110,16 @@ struct Accumulator {
 int main(int argc, char** argv) {
     const std::string scene_path = argc > 1 ? argv[1] : "scene";
     const std::string out_path = argc > 2 ? argv[2] : "target/out.ppm";
-    const int gpu = argc > 3 ? std::atoi(argv[3]) : 0;
+    std::vector<int> gpus;
+    for (const char* c = argc > 3 ? argv[3] : "0"; *c;) {
+        char* end = nullptr;
+        gpus.push_back(static_cast<int>(std::strtol(c, &end, 10)));
+        if (end == c) {
+            std::fprintf(stderr, "bad GPU list %s\n", argv[3]);
+            return 1;
+        }
+        c = *end == ',' ? end + 1 : end;
+    }
     uint32_t tile_edge = argc > 4 ? static_cast<uint32_t>(std::strtoul(argv[4], nullptr, 10)) : 0;
     const std::string acc_path = argc > 5 ? argv[5] : "";
 
@@ -117,12 +131,13 @@ int main(int argc, char** argv) {
     std::stringstream text;
     text << in.rdbuf();
 
-    RtContext* ctx = nullptr;
-    int rc = rt_create(gpu, &ctx);
+    RtGroup* group = nullptr;
+    int rc = rt_group_create(gpus.data(), static_cast<uint32_t>(gpus.size()), &group);
     if (rc != RT_OK) {
-        std::fprintf(stderr, "no usable GPU (rt_create returned %d)\n", rc);
+        std::fprintf(stderr, "no usable GPU (%d): %s\n", rc, rt_group_last_error(nullptr));
         return 1;
     }
+    RtContext* ctx = rt_group_member(group, 0);
 
     // scene ingest on the host, with the triangle BVH built on the GPU (same tree)
     char err[1024] = {0};
@@ -144,7 +159,7 @@ int main(int argc, char** argv) {
         return 1;
     }
 
-    rc = rt_upload_scene(ctx, &desc);
+    rc = rt_group_upload_scene(group, &desc);
     const uint64_t n_pixels = static_cast<uint64_t>(params.width) * params.height;
     if (tile_edge == 0 && n_pixels > (1ull << 24)) tile_edge = 4096;
     if (rc == RT_OK && !acc_path.empty()) {
@@ -200,7 +215,7 @@ int main(int argc, char** argv) {
         }
         acc.close();
     } else if (rc == RT_OK && (tile_edge == 0 || (tile_edge >= params.width && tile_edge >= params.height))) {
-        rc = rt_render(ctx, &params, rth_image_pixels(image), progress, nullptr);
+        rc = rt_group_render(group, &params, rth_image_pixels(image), progress, nullptr);
     } else if (rc == RT_OK) {
         // lib.rs:206-211,233-235: passes outermost, so the file is a whole image after each
         const uint32_t chunk = params.incremental ? params.incremental : params.samples_per_pixel;
@@ -226,20 +241,23 @@ int main(int argc, char** argv) {
                     tp.tile_w = std::min(tile_edge, params.width - x);
                     tp.tile_h = std::min(tile_edge, params.height - y);
                     if (running) rth_image_read_tile(image, x, y, tp.tile_w, tp.tile_h, tile.data());
-                    rc = rt_render(ctx, &tp, tile.data(), nullptr, nullptr);
+                    rc = rt_group_render(group, &tp, tile.data(), nullptr, nullptr);
                     if (rc == RT_OK) rth_image_write_tile(image, x, y, tp.tile_w, tp.tile_h, tile.data());
                 }
             if (rc == RT_OK) progress(first_pass + (pass + 1) * chunk, nullptr);  // lib.rs:238-246
         }
     }
-    if (rc != RT_OK) std::fprintf(stderr, "\nrender failed (%d): %s\n", rc, rt_last_error(ctx));
+    if (rc != RT_OK) {
+        const char* why = rt_group_last_error(group);
+        std::fprintf(stderr, "\nrender failed (%d): %s\n", rc, why[0] ? why : rt_last_error(ctx));
+    }
     else std::printf("\n");
 
     RtStats st;
-    if (rc == RT_OK && rt_get_stats(ctx, &st) == RT_OK && st.render_ms > 0)
+    if (rc == RT_OK && rt_group_get_stats(group, &st) == RT_OK && st.render_ms > 0)
         std::fprintf(stderr, "%llu rays in %.1f ms: %.1f Mrays/s\n", (unsigned long long)st.segments, st.render_ms,
                      st.segments / st.render_ms / 1e3);
-    rt_destroy(ctx);
+    rt_group_destroy(group);
     rth_image_flush(image);
     rth_image_close(image);
     rth_free_scene(scene);

@@ -93,6 +93,10 @@ def test_command_line_renderer_tiles_large_frames(asset_root, tmp_path):
     subprocess.run([exe, str(scene_file), out_b, "0", "32"], cwd=asset_root, check=True, env=env, timeout=120)
     a, b = open(out_a, "rb").read(), open(out_b, "rb").read()
     assert a.startswith(b"P6\n80 50 255\n") and a == b
+    # a list of GPUs (here GPU 0 three times) shares every pass's samples: the same file
+    out_c = str(tmp_path / "c.ppm")
+    subprocess.run([exe, str(scene_file), out_c, "0,0,0", "32"], cwd=asset_root, check=True, env=env, timeout=120)
+    assert open(out_c, "rb").read() == a
     scene = scenes.room(asset_root, w=80, h=50, spp=4, bounces=8, incremental=2)
     cpu, _ = O.render(scene, scene.params, threads=4)
     assert a[len(b"P6\n80 50 255\n"):] == cpu.tobytes()
