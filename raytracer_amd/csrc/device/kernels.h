@@ -332,7 +332,8 @@ struct TraceArgs {
     uint32_t refill_min;     // idle lanes that trigger a refill from the queue (1..64)
     int bounds_fast;         // every box coordinate is 0 or has magnitude in [2^-60, 2^59)
     unsigned long long* counters;  // [0] branch visits, [1] shape tests (COUNT only)
-    unsigned long long* wave_tallies;  // six diagnostic words, then 32 of branch visits by depth band; triangle family only (COUNT only)
+    unsigned long long* wave_tallies;  // six diagnostic words, triangle family only (COUNT only)
+    unsigned long long* visit_bands;   // 32 words: branch visits by depth band (COUNT only; null unless asked for: one atomic per visit)
 };
 
 // A workgroup is WAVES independent waves that share one thing: a copy in LDS of
@@ -571,7 +572,7 @@ __global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num
                 if (COUNT) {
                     ++n_branch;
                     // diagnostic: visits by depth band of the breadth-first numbering (records 2^k - 1 .. 2^(k+1) - 2)
-                    if (a.wave_tallies) atomicAdd(&a.wave_tallies[6 + (31 - __clz(static_cast<int>(item + 1u)))], 1ull);
+                    if (a.visit_bands) atomicAdd(&a.visit_bands[31 - __clz(static_cast<int>(item + 1u))], 1ull);
                 }
                 // bvh.rs:268-285.  With both children hit the farther one is pushed and
                 // the nearer kept in hand; on equal distances child 1 is the nearer.

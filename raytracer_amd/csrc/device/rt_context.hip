@@ -125,6 +125,7 @@ struct RtContext {
     uint32_t tune_cache_nodes = 144;  // branch records each multi-wave workgroup copies to LDS
     bool tune_share = true;  // deal pending (ray, triangle) pairs out to all lanes
     bool opt_count = false, opt_time = false, opt_fast_slab = false;
+    bool debug_tallies = std::getenv("RT_MI355_DEBUG_TALLIES") != nullptr;  // slow diagnostics of the counting kernels
     uint64_t opt_samples_in_flight = 0;  // 0 = automatic
     std::vector<hipEvent_t> events;      // pairs around timed launches
     size_t events_used = 0;
@@ -526,6 +527,7 @@ int launch_trace(RtContext* ctx, const DQueue& q, const uint32_t* n_rays, uint32
         a.bounds_fast = ctx->fam[kind].bounds_fast ? 1 : 0;
         a.counters = ctx->d_stats + 1 + 2 * kind;  // [branch visits, shape tests] of this family
         a.wave_tallies = kind == RT_SHAPE_TRIANGLE ? ctx->d_stats + 9 : nullptr;
+        a.visit_bands = kind == RT_SHAPE_TRIANGLE && ctx->debug_tallies ? ctx->d_stats + 15 : nullptr;
         const bool timed = ctx->opt_time && kind == RT_SHAPE_TRIANGLE;
         if (timed) {
             if (ctx->events_used + 2 > ctx->events.size()) {
