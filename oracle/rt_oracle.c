@@ -318,8 +318,10 @@ static v3 color_sample(const RtSceneDesc* sc, const RtMaterial* m, const float u
     for (int k = 0; k < 2; ++k) {
         const float e = c[k] * (float)(dim[k] - 1);
         const float e0f = floorf(e);
-        /* `as usize`: NaN and negatives to 0, saturating above */
-        size_t e0 = !(e0f > 0.0f) ? 0 : (e0f >= 1.8446744e19f ? SIZE_MAX : (size_t)e0f);
+        /* `as usize`: NaN and negatives to 0, saturating above.  c is in [0, 1], so e0 never exceeds
+         * dim - 1 (the reference would panic on the index if it did); the GPU kernel clamps there
+         * instead of faulting, and so does this function, so that the two state the same thing. */
+        size_t e0 = !(e0f > 0.0f) ? 0 : (e0f >= (float)(dim[k] - 1) ? (size_t)dim[k] - 1 : (size_t)e0f);
         size_t e1 = e0 + 1 < (size_t)dim[k] - 1 ? e0 + 1 : (size_t)dim[k] - 1;
         i0[k] = e0;
         i1[k] = e1;
