@@ -235,6 +235,14 @@ typedef enum RtOption {
      * and the closest hit are equally far to rounding; hit distances themselves, triangle
      * tests and shading stay exact.  Ignored while RT_OPT_COUNT_TRAVERSAL is on. */
     RT_OPT_FAST_SLAB = 15,
+    /* The whole bounce loop of a batch as one launch in which every wave takes its own block of
+     * paths through all bounces (no launch, counter or barrier per bounce): 0 never, 1 whenever
+     * the scene allows it (triangles traversed; spheres and planes absent or few enough to be
+     * scanned where rays are created), 2 (default) then and for batches below 3 * 2^22 paths,
+     * where it is the faster loop (several times faster for previews and single-sample passes).
+     * Results do not depend on it. */
+    RT_OPT_FUSED_LOOP = 17,
+    RT_OPT_PATH_GROUP = 18, /* tuning of that launch: paths a wave takes through all bounces at a time (multiple of 64; default 16384) */
     RT_OPT_TRACE_WAVES_PER_CU = 12 /* traversal waves resident per compute unit (0 = as many as fit, else 1..32): leaves room for kernels of another context on the same GPU */
 } RtOption;
 

@@ -247,35 +247,47 @@ __device__ __forceinline__ bool magnitude_in(float v, float lo, float hi) {
 // kernel and the queues are far larger than the caches, so they are marked
 // non-temporal to leave cache space to the scene data (nodes, surface records,
 // texels), which is re-read.
+//
+// Every pointer these helpers and in_global() are given points into device memory.  Saying so
+// (address space 1) matters where the pointer itself was read from memory rather than passed as
+// a kernel argument (k_path): the compiler then cannot tell, and would emit flat loads, which
+// reach memory the slow way round and count against the LDS wait counter as well.
+#define RT_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ T* in_global(T* p) {
+    __builtin_assume(!__builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void*)p));
+    __builtin_assume(!__builtin_amdgcn_is_private((const __attribute__((address_space(0))) void*)p));
+    return p;
+}
 typedef float nt_f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t nt_u2 __attribute__((ext_vector_type(2)));
 __device__ inline float4 stream_load(const float4* p) {
-    const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
+    const nt_f4 v = __builtin_nontemporal_load((const RT_GLOBAL nt_f4*)p);
     return make_float4(v.x, v.y, v.z, v.w);
 }
 typedef float nt_f3 __attribute__((ext_vector_type(3)));
 typedef nt_f3 nt_f3_packed __attribute__((aligned(4)));  // 12 bytes in memory, dword-aligned: one global_load_dwordx3
 __device__ inline F3 stream_load(const P3* p) {
-    const nt_f3 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f3_packed*>(p));
+    const nt_f3 v = __builtin_nontemporal_load((const RT_GLOBAL nt_f3_packed*)p);
     return F3{v.x, v.y, v.z};
 }
 __device__ inline void stream_store(P3* p, F3 v) {
-    __builtin_nontemporal_store(nt_f3{v.x, v.y, v.z}, reinterpret_cast<nt_f3_packed*>(p));
+    __builtin_nontemporal_store(nt_f3{v.x, v.y, v.z}, (RT_GLOBAL nt_f3_packed*)p);
 }
 __device__ inline uint2 stream_load(const uint2* p) {
-    const nt_u2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u2*>(p));
+    const nt_u2 v = __builtin_nontemporal_load((const RT_GLOBAL nt_u2*)p);
     return make_uint2(v.x, v.y);
 }
-__device__ inline uint32_t stream_load(const uint32_t* p) { return __builtin_nontemporal_load(p); }
-__device__ inline float stream_load(const float* p) { return __builtin_nontemporal_load(p); }
+__device__ inline uint32_t stream_load(const uint32_t* p) { return __builtin_nontemporal_load((const RT_GLOBAL uint32_t*)p); }
+__device__ inline float stream_load(const float* p) { return __builtin_nontemporal_load((const RT_GLOBAL float*)p); }
 __device__ inline void stream_store(float4* p, float4 v) {
-    __builtin_nontemporal_store(nt_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_f4*>(p));
+    __builtin_nontemporal_store(nt_f4{v.x, v.y, v.z, v.w}, (RT_GLOBAL nt_f4*)p);
 }
 __device__ inline void stream_store(uint2* p, uint2 v) {
-    __builtin_nontemporal_store(nt_u2{v.x, v.y}, reinterpret_cast<nt_u2*>(p));
+    __builtin_nontemporal_store(nt_u2{v.x, v.y}, (RT_GLOBAL nt_u2*)p);
 }
-__device__ inline void stream_store(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, p); }
-__device__ inline void stream_store(float* p, float v) { __builtin_nontemporal_store(v, p); }
+__device__ inline void stream_store(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, (RT_GLOBAL uint32_t*)p); }
+__device__ inline void stream_store(float* p, float v) { __builtin_nontemporal_store(v, (RT_GLOBAL float*)p); }
 
 // Inclusive scans over the 64 lanes of a wave with data-parallel-primitive moves
 // (row shifts inside each row of 16 lanes, then the last lane of row 0/2 and of
@@ -357,30 +369,18 @@ __host__ __device__ inline size_t trace_lds_per_wave(uint32_t lds_slots) {
 // places, which can change the order of visits and the outcome of a cull where a
 // box's distance and the closest hit's agree to rounding; triangle tests and
 // everything else stay exact.
-template <int KIND, bool COUNT, bool SHARE, int WAVES, bool FASTSLAB = false>
-__global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(COUNT ? 4 : 8))) k_trace(TraceArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    float4* const s_nodes = reinterpret_cast<float4*>(s_raw);
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    unsigned char* const s_wave = s_raw + static_cast<size_t>(a.cache_nodes) * sizeof(DNode) + wave * trace_lds_per_wave(a.lds_slots);
-    uint2* const s_stack = reinterpret_cast<uint2*>(s_wave);  // [lds_slots][64]; then 64 result keys, 64 marks (SHARE)
-    unsigned long long* const s_res = reinterpret_cast<unsigned long long*>(s_stack + a.lds_slots * kTraceBlock);
-    uint32_t* const s_mark = reinterpret_cast<uint32_t*>(s_res + kTraceBlock);
-    const uint32_t gtid = blockIdx.x * (kTraceBlock * WAVES) + threadIdx.x;
-    const uint32_t n = *a.n_rays;
-    const DNode* __restrict__ nodes = a.fam.nodes;
-    const uint32_t cache_nodes = WAVES > 1 ? a.cache_nodes : 0u;
-    if (WAVES > 1) {
-        const float4* src = reinterpret_cast<const float4*>(nodes);
-        for (uint32_t k = threadIdx.x; k < cache_nodes * 4u; k += kTraceBlock * WAVES)
-            s_nodes[(k & 3u) * cache_nodes + (k >> 2)] = src[k];
-        __syncthreads();
-    }
-    // Reservation size: large for long queues (few atomics), one wave's worth for
-    // short ones so that the rays still spread over all waves of the grid.
-    const uint32_t chunk = min(a.chunk_max, max(64u, (n / (2u * gridDim.x * WAVES)) & ~63u));
+// The traversal loop of one wave (see the comment above): rays are entries of `q`,
+// taken from the block [pool_first, pool_last) the wave holds and then, unless
+// `no_more`, from further blocks of `chunk` entries reserved on a.cursor up to
+// entry `n`.  The wave's LDS areas and the workgroup's copy of the tree's top are
+// set up by the calling kernel.
+template <int KIND, bool COUNT, bool SHARE, int WAVES, bool FASTSLAB>
+__device__ __forceinline__ void trace_loop(const TraceArgs& a, const DQueue& q, const float4* s_nodes, uint2* s_stack,
+                                           unsigned long long* s_res, uint32_t* s_mark, uint32_t lane, uint32_t gtid,
+                                           uint32_t cache_nodes, uint32_t n, uint32_t chunk, uint32_t pool_first,
+                                           uint32_t pool_last, bool no_more) {
     const int lds_slots = static_cast<int>(a.lds_slots);
+    const DNode* __restrict__ nodes = a.fam.nodes;
 
     auto stack_store = [&](int slot, float dist, uint32_t ref) {
         // One 64-bit value, so that neither store can be split in two and the halves
@@ -402,8 +402,8 @@ __global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num
         return e;
     };
 
-    bool active = false, exhausted = false, fast = false;
-    uint32_t pool_next = 0, pool_end = 0;  // wave-uniform: rays reserved for this wave
+    bool active = false, exhausted = no_more, fast = false;
+    uint32_t pool_next = pool_first, pool_end = pool_last;  // wave-uniform: rays reserved for this wave
     uint32_t ray = 0, best_i = kHitNone;
     int sp = 0;
     F3 o = f3(0, 0, 0), d = f3(0, 0, 0);
@@ -430,8 +430,8 @@ __global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num
             if (item == kItemNone) {
                 // bvh.rs:300 + lib.rs:333: keep the earlier family on equal distance.
                 if (best_t < prior_t) {
-                    stream_store(&a.q.hit_t[ray], best_t);
-                    stream_store(&a.q.hit_id[ray], (static_cast<uint32_t>(KIND) << kHitKindShift) | best_i);
+                    stream_store(&q.hit_t[ray], best_t);
+                    stream_store(&q.hit_id[ray], (static_cast<uint32_t>(KIND) << kHitKindShift) | best_i);
                 }
                 active = false;
             }
@@ -458,9 +458,9 @@ __global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num
                 if (!active && rank < take) {
                     const uint32_t idx = pool_next + rank;
                     ray = idx;
-                    o = stream_load(&a.q.origin[idx]);  // read once: kept out of the way of the node data in the caches
-                    d = stream_load(&a.q.direction[idx]);
-                    prior_t = stream_load(&a.q.hit_t[idx]);
+                    o = stream_load(&q.origin[idx]);  // read once: kept out of the way of the node data in the caches
+                    d = stream_load(&q.direction[idx]);
+                    prior_t = stream_load(&q.hit_t[idx]);
                     best_t = kInfinity;
                     best_i = kHitNone;
                     sp = 0;
@@ -697,6 +697,31 @@ __global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num
     }
 }
 
+template <int KIND, bool COUNT, bool SHARE, int WAVES, bool FASTSLAB = false>
+__global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(COUNT ? 4 : 8))) k_trace(TraceArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    float4* const s_nodes = reinterpret_cast<float4*>(s_raw);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned char* const s_wave = s_raw + static_cast<size_t>(a.cache_nodes) * sizeof(DNode) + wave * trace_lds_per_wave(a.lds_slots);
+    uint2* const s_stack = reinterpret_cast<uint2*>(s_wave);  // [lds_slots][64]; then 64 result keys, 64 marks (SHARE)
+    unsigned long long* const s_res = reinterpret_cast<unsigned long long*>(s_stack + a.lds_slots * kTraceBlock);
+    uint32_t* const s_mark = reinterpret_cast<uint32_t*>(s_res + kTraceBlock);
+    const uint32_t gtid = blockIdx.x * (kTraceBlock * WAVES) + threadIdx.x;
+    const uint32_t n = *a.n_rays;
+    const uint32_t cache_nodes = WAVES > 1 ? a.cache_nodes : 0u;
+    if (WAVES > 1) {
+        const float4* src = reinterpret_cast<const float4*>(a.fam.nodes);
+        for (uint32_t k = threadIdx.x; k < cache_nodes * 4u; k += kTraceBlock * WAVES)
+            s_nodes[(k & 3u) * cache_nodes + (k >> 2)] = src[k];
+        __syncthreads();
+    }
+    // Reservation size: large for long queues (few atomics), one wave's worth for
+    // short ones so that the rays still spread over all waves of the grid.
+    const uint32_t chunk = min(a.chunk_max, max(64u, (n / (2u * gridDim.x * WAVES)) & ~63u));
+    trace_loop<KIND, COUNT, SHARE, WAVES, FASTSLAB>(a, a.q, s_nodes, s_stack, s_res, s_mark, lane, gtid, cache_nodes, n, chunk, 0u, 0u, false);
+}
+
 // --------------------------------------------------- inlined small families
 
 // Nearest hit of a new ray among the sphere and plane families that are small
@@ -712,7 +737,7 @@ __device__ __forceinline__ void seed_hit(const DScene& sc, F3 o, F3 d, float& t_
     const uint32_t ns = sc.inline_count[0], np = sc.inline_count[1];
     for (uint32_t i = 0; i < ns; ++i) {
         float t;
-        if (sphere_hit(static_cast<const DSphere*>(sc.family[0].shapes)[i], o, d, t) && t < best_t) {
+        if (sphere_hit(in_global(static_cast<const DSphere*>(sc.family[0].shapes))[i], o, d, t) && t < best_t) {
             best_t = t;
             best_id = i;  // kind 0
         }
@@ -721,7 +746,7 @@ __device__ __forceinline__ void seed_hit(const DScene& sc, F3 o, F3 d, float& t_
     uint32_t plane_i = kHitNone;
     for (uint32_t i = 0; i < np; ++i) {
         float t;
-        if (plane_hit(static_cast<const DPlane*>(sc.family[1].shapes)[i], o, d, t) && t < plane_t) {
+        if (plane_hit(in_global(static_cast<const DPlane*>(sc.family[1].shapes))[i], o, d, t) && t < plane_t) {
             plane_t = t;
             plane_i = i;
         }
@@ -755,13 +780,22 @@ struct FrameArgs {
 // The launch covers paths [first_path, first_path + n_paths) of the batch and
 // writes them to queue entries [0, n_paths): a batch may be split over several
 // queues; a path's result slot is its number in the whole batch.
+//
+// `deal_waves` (k_path's launches; 0 otherwise): the paths are dealt out in blocks of 64 to that
+// many waves in turn, wave w's blocks stored one after the other from entry w * per_wave on, so
+// that every wave's share is spread over the whole frame (neighbouring pixels have paths of
+// similar length; contiguous shares would leave some waves with all the long ones).
 __global__ void k_raygen(FrameArgs f, DScene sc, DQueue q, uint32_t first_path, uint32_t n_paths, uint32_t n_pixels,
                          unsigned long long first_sample, int jitter, uint32_t* n_rays_out,
-                         unsigned long long* test_counters) {
-    const uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
+                         unsigned long long* test_counters, uint32_t deal_waves = 0, uint32_t per_wave = 0) {
+    uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
     if (local == 0) *n_rays_out = n_paths;
     if (local >= n_paths) return;
     const uint32_t path = first_path + local;
+    if (deal_waves) {
+        const uint32_t block = local >> 6;
+        local = (block % deal_waves) * per_wave + (block / deal_waves) * 64u + (local & 63u);
+    }
     const uint32_t j = path / n_pixels, pix = path - j * n_pixels;
     const uint32_t x = f.x0 + pix % f.tile_w, y = f.y0 + pix / f.tile_w;
     const unsigned long long sample = first_sample + j;
@@ -853,7 +887,7 @@ __device__ __forceinline__ F3 color_sample(const DScene& sc, const DMaterial& m,
         i1[k] = min(e0 + 1u, dim[k] - 1u);
         de[k] = e - e0f;
     }
-    const uint32_t* tex = sc.texels + m.tex_first;
+    const uint32_t* tex = in_global(sc.texels) + m.tex_first;
     const size_t w = m.tex_width;
     // byte -> byte/255 (vec3.rs:515-520) through a 256-entry table of exact quotients
     auto texel = [&](uint32_t x, uint32_t y) {
@@ -879,9 +913,149 @@ struct ShadeArgs {
     int last_bounce;        // this bounce is max_bounces-1
 };
 
-// One iteration of the bounce loop after the nearest hit is known,
-// lib.rs:335-371, with Material::scatter (material.rs:23-100) and the surface
-// attributes of shapes.rs:91-99,157-165,264-326 inlined.
+// One iteration of the bounce loop for queue entry i after its nearest hit is
+// known, lib.rs:335-371, with Material::scatter (material.rs:23-100) and the
+// surface attributes of shapes.rs:91-99,157-165,264-326 inlined.  A path that
+// ends here leaves its radiance in result[slot]; for one that goes on (returns
+// true) the next ray's origin and direction, the throughput, the generator state
+// and the result slot are handed back.  `unit_of_byte`: 256 floats, byte/255.
+__device__ __forceinline__ bool shade_entry(const DScene& scene, const DQueue& cur, uint32_t i, float4* result, int last_bounce,
+                                            const float* unit_of_byte, F3& no, F3& nd, F3& thr, unsigned long long& rng,
+                                            uint32_t& slot, unsigned long long& hits) {
+    bool alive = false;  // continues into the next bounce
+    const F3 o = stream_load(&cur.origin[i]), d = stream_load(&cur.direction[i]);
+    thr = stream_load(&cur.throughput[i]);
+    slot = stream_load(&cur.slot[i]);
+    const uint32_t id = stream_load(&cur.hit_id[i]);
+    if (id == kHitNone) {
+        // lib.rs:337-345
+        const float s = 0.5f * (d.y + 1.0f);
+        const F3 sky = f3(0.2f, 0.2f, 0.8f) * (1.0f - s) + f3(1.0f, 1.0f, 1.0f) * s;
+        thr = thr * sky;
+        in_global(result)[slot] = make_float4(thr.x, thr.y, thr.z, 0.0f);
+    } else {
+        ++hits;
+        const uint2 rs = stream_load(&cur.rng[i]);
+        rng = (static_cast<unsigned long long>(rs.y) << 32) | rs.x;
+        const float t = stream_load(&cur.hit_t[i]);
+        const uint32_t kind = id >> kHitKindShift, prim = id & kHitPrimMask;
+        const F3 p = o + d * t;  // bvh.rs:303
+        F3 normal;
+        float uv0 = 0.0f, uv1 = 0.0f;
+        uint32_t mat_i;
+        if (kind == 0) {
+            const DSphere s = in_global(static_cast<const DSphere*>(scene.family[0].shapes))[prim];
+            normal = normalize(p - f3(s.center));
+            mat_i = in_global(scene.sphere_material)[prim];
+        } else if (kind == 1) {
+            const DPlane pl = in_global(static_cast<const DPlane*>(scene.family[1].shapes))[prim];
+            normal = f3(pl.normal);
+            mat_i = in_global(scene.plane_material)[prim];
+        } else {
+            const float4* sp4 = in_global(reinterpret_cast<const float4*>(scene.tri_surface + prim));
+            const float4 w0 = sp4[0], w1 = sp4[1], w2 = sp4[2], w7 = sp4[7];
+            const F3 ta = f3(w0.x, w0.y, w0.z), e1 = f3(w0.w, w1.x, w1.y), e2 = f3(w1.z, w1.w, w2.x);
+            const uint32_t mf = __float_as_uint(w7.x);
+            mat_i = mf & kTriMaterialMask;
+            if (!(mf & kTriHasBary)) {
+                normal = normalize(cross(e1, e2));
+            } else {
+                // shapes.rs:210-227
+                const float4 w3 = sp4[3], w4 = sp4[4], w5 = sp4[5], pre = sp4[6];
+                const F3 ap = p - ta;
+                const float d20 = dot(ap, e1), d21 = dot(ap, e2);
+                const float bv = (pre.z * d20 - pre.y * d21) / pre.w;
+                const float bw = (pre.x * d21 - pre.y * d20) / pre.w;
+                const float bu = 1.0f - bv - bw;
+                if (mf & kTriHasNormals) {
+                    const F3 n0 = f3(w2.y, w2.z, w2.w), n1 = f3(w3.x, w3.y, w3.z), n2 = f3(w3.w, w4.x, w4.y);
+                    normal = normalize((n0 * bu + n1 * bv) + n2 * bw);
+                } else {
+                    normal = normalize(cross(e1, e2));
+                }
+                if (mf & kTriHasUv) {
+                    uv0 = (w4.z * bu + w5.x * bv) + w5.z * bw;
+                    uv1 = (w4.w * bu + w5.y * bv) + w5.w * bw;
+                }
+            }
+        }
+        const DMaterial m = in_global(scene.materials)[mat_i];
+        no = p + normal * 1e-4f;  // material.rs:29
+        int what = 0;            // 0 scattered, 1 absorbed, 2 light
+        if (m.kind == 0) {
+            const F3 dir = normalize(normal + random_unit(rng));
+            const bool near_zero = fabsf(dir.x) < kEpsilon && fabsf(dir.y) < kEpsilon && fabsf(dir.z) < kEpsilon;
+            nd = near_zero ? normal : dir;
+        } else if (m.kind == 1) {
+            const F3 refl = reflect(d, normal);
+            if (m.param == 0.0f) {
+                nd = refl;
+            } else {
+                nd = normalize(refl + random_unit(rng) * m.param);
+                if (!(dot(nd, normal) > 0.0f)) what = 1;
+            }
+        } else if (m.kind == 2) {
+            float eta;
+            F3 nn;
+            if (dot(d, normal) < 0.0f) {
+                eta = 1.0f / m.param;
+                nn = normal;
+            } else {
+                eta = m.param;
+                nn = -normal;
+            }
+            const float cosv = fminf(dot(-d, nn), 1.0f);
+            const float sinv = sqrtf(1.0f - cosv * cosv);
+            float r0 = (1.0f - eta) / (1.0f + eta);
+            r0 = r0 * r0;
+            const float x = 1.0f - cosv;
+            const float x5 = x * ((x * x) * (x * x));
+            const float reflectance = r0 + (1.0f - r0) * x5;
+            bool do_reflect = eta * sinv > 1.0f;
+            if (!do_reflect) do_reflect = rng_f32(rng) < reflectance;  // draw only without total reflection
+            if (do_reflect) {
+                nd = reflect(d, nn);
+            } else {
+                const F3 perp = (d + nn * cosv) * eta;
+                const float disc = 1.0f - eta * eta * (1.0f - cosv * cosv);
+                nd = perp + nn * (-sqrtf(disc));
+            }
+        } else {
+            what = 2;
+        }
+        if (what == 1) {
+            in_global(result)[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // lib.rs:359-362
+        } else {
+            thr = thr * color_sample(scene, m, uv0, uv1, unit_of_byte);
+            if (what == 2 || last_bounce) {
+                // a light ends the path; so does the bounce limit, which
+                // returns the throughput reached so far (lib.rs:313,374)
+                in_global(result)[slot] = make_float4(thr.x, thr.y, thr.z, 0.0f);
+            } else {
+                alive = true;
+            }
+        }
+    }
+    return alive;
+}
+
+// A surviving path's entry in the next bounce's queue: the new ray, the state that
+// travels with the path, and the nearest hit among the families scanned on the spot.
+__device__ __forceinline__ void store_survivor(const DScene& scene, const DQueue& next, uint32_t dst, F3 no, F3 nd, F3 thr,
+                                               unsigned long long rng, uint32_t slot, unsigned long long* test_counters) {
+    stream_store(&next.origin[dst], no);
+    stream_store(&next.direction[dst], nd);
+    stream_store(&next.throughput[dst], thr);
+    stream_store(&next.rng[dst], make_uint2(static_cast<uint32_t>(rng), static_cast<uint32_t>(rng >> 32)));
+    stream_store(&next.slot[dst], slot);
+    float ht;
+    uint32_t hid;
+    seed_hit(scene, no, nd, ht, hid, test_counters);
+    stream_store(&next.hit_t[dst], ht);
+    stream_store(&next.hit_id[dst], hid);
+}
+
+// shade_entry over a whole queue; the surviving paths are compacted into `next`.
 __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
     __shared__ float s_unit[256];      // byte/255, all 256 quotients by true division
     __shared__ uint32_t s_wave_live[4];
@@ -896,125 +1070,10 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
     unsigned long long my_hits = 0;
     for (uint32_t r = 0; r < rounds; ++r) {
         const uint32_t i = r * stride + blockIdx.x * blockDim.x + threadIdx.x;
-        bool alive = false;  // continues into the next bounce
         F3 no = f3(0, 0, 0), nd = f3(0, 0, 0), thr = f3(0, 0, 0);
         unsigned long long rng = 0;
         uint32_t slot = 0;
-        if (i < n) {
-            const F3 o = stream_load(&a.cur.origin[i]), d = stream_load(&a.cur.direction[i]);
-            thr = stream_load(&a.cur.throughput[i]);
-            slot = stream_load(&a.cur.slot[i]);
-            const uint32_t id = stream_load(&a.cur.hit_id[i]);
-            if (id == kHitNone) {
-                // lib.rs:337-345
-                const float s = 0.5f * (d.y + 1.0f);
-                const F3 sky = f3(0.2f, 0.2f, 0.8f) * (1.0f - s) + f3(1.0f, 1.0f, 1.0f) * s;
-                thr = thr * sky;
-                a.result[slot] = make_float4(thr.x, thr.y, thr.z, 0.0f);
-            } else {
-                ++my_hits;
-                const uint2 rs = stream_load(&a.cur.rng[i]);
-                rng = (static_cast<unsigned long long>(rs.y) << 32) | rs.x;
-                const float t = stream_load(&a.cur.hit_t[i]);
-                const uint32_t kind = id >> kHitKindShift, prim = id & kHitPrimMask;
-                const F3 p = o + d * t;  // bvh.rs:303
-                F3 normal;
-                float uv0 = 0.0f, uv1 = 0.0f;
-                uint32_t mat_i;
-                if (kind == 0) {
-                    const DSphere s = static_cast<const DSphere*>(a.scene.family[0].shapes)[prim];
-                    normal = normalize(p - f3(s.center));
-                    mat_i = a.scene.sphere_material[prim];
-                } else if (kind == 1) {
-                    const DPlane pl = static_cast<const DPlane*>(a.scene.family[1].shapes)[prim];
-                    normal = f3(pl.normal);
-                    mat_i = a.scene.plane_material[prim];
-                } else {
-                    const float4* sp4 = reinterpret_cast<const float4*>(a.scene.tri_surface + prim);
-                    const float4 w0 = sp4[0], w1 = sp4[1], w2 = sp4[2], w7 = sp4[7];
-                    const F3 ta = f3(w0.x, w0.y, w0.z), e1 = f3(w0.w, w1.x, w1.y), e2 = f3(w1.z, w1.w, w2.x);
-                    const uint32_t mf = __float_as_uint(w7.x);
-                    mat_i = mf & kTriMaterialMask;
-                    if (!(mf & kTriHasBary)) {
-                        normal = normalize(cross(e1, e2));
-                    } else {
-                        // shapes.rs:210-227
-                        const float4 w3 = sp4[3], w4 = sp4[4], w5 = sp4[5], pre = sp4[6];
-                        const F3 ap = p - ta;
-                        const float d20 = dot(ap, e1), d21 = dot(ap, e2);
-                        const float bv = (pre.z * d20 - pre.y * d21) / pre.w;
-                        const float bw = (pre.x * d21 - pre.y * d20) / pre.w;
-                        const float bu = 1.0f - bv - bw;
-                        if (mf & kTriHasNormals) {
-                            const F3 n0 = f3(w2.y, w2.z, w2.w), n1 = f3(w3.x, w3.y, w3.z), n2 = f3(w3.w, w4.x, w4.y);
-                            normal = normalize((n0 * bu + n1 * bv) + n2 * bw);
-                        } else {
-                            normal = normalize(cross(e1, e2));
-                        }
-                        if (mf & kTriHasUv) {
-                            uv0 = (w4.z * bu + w5.x * bv) + w5.z * bw;
-                            uv1 = (w4.w * bu + w5.y * bv) + w5.w * bw;
-                        }
-                    }
-                }
-                const DMaterial m = a.scene.materials[mat_i];
-                no = p + normal * 1e-4f;  // material.rs:29
-                int what = 0;            // 0 scattered, 1 absorbed, 2 light
-                if (m.kind == 0) {
-                    const F3 dir = normalize(normal + random_unit(rng));
-                    const bool near_zero = fabsf(dir.x) < kEpsilon && fabsf(dir.y) < kEpsilon && fabsf(dir.z) < kEpsilon;
-                    nd = near_zero ? normal : dir;
-                } else if (m.kind == 1) {
-                    const F3 refl = reflect(d, normal);
-                    if (m.param == 0.0f) {
-                        nd = refl;
-                    } else {
-                        nd = normalize(refl + random_unit(rng) * m.param);
-                        if (!(dot(nd, normal) > 0.0f)) what = 1;
-                    }
-                } else if (m.kind == 2) {
-                    float eta;
-                    F3 nn;
-                    if (dot(d, normal) < 0.0f) {
-                        eta = 1.0f / m.param;
-                        nn = normal;
-                    } else {
-                        eta = m.param;
-                        nn = -normal;
-                    }
-                    const float cosv = fminf(dot(-d, nn), 1.0f);
-                    const float sinv = sqrtf(1.0f - cosv * cosv);
-                    float r0 = (1.0f - eta) / (1.0f + eta);
-                    r0 = r0 * r0;
-                    const float x = 1.0f - cosv;
-                    const float x5 = x * ((x * x) * (x * x));
-                    const float reflectance = r0 + (1.0f - r0) * x5;
-                    bool do_reflect = eta * sinv > 1.0f;
-                    if (!do_reflect) do_reflect = rng_f32(rng) < reflectance;  // draw only without total reflection
-                    if (do_reflect) {
-                        nd = reflect(d, nn);
-                    } else {
-                        const F3 perp = (d + nn * cosv) * eta;
-                        const float disc = 1.0f - eta * eta * (1.0f - cosv * cosv);
-                        nd = perp + nn * (-sqrtf(disc));
-                    }
-                } else {
-                    what = 2;
-                }
-                if (what == 1) {
-                    a.result[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // lib.rs:359-362
-                } else {
-                    thr = thr * color_sample(a.scene, m, uv0, uv1, s_unit);
-                    if (what == 2 || a.last_bounce) {
-                        // a light ends the path; so does the bounce limit, which
-                        // returns the throughput reached so far (lib.rs:313,374)
-                        a.result[slot] = make_float4(thr.x, thr.y, thr.z, 0.0f);
-                    } else {
-                        alive = true;
-                    }
-                }
-            }
-        }
+        const bool alive = i < n && shade_entry(a.scene, a.cur, i, a.result, a.last_bounce, s_unit, no, nd, thr, rng, slot, my_hits);
         // compaction: one atomic per workgroup and round; survivors keep their order
         const unsigned long long live = __ballot(alive);
         if (lane == 0) s_wave_live[wave] = __popcll(live);
@@ -1027,22 +1086,151 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
         if (alive) {
             uint32_t dst = s_block_base + bits_below_lane(live);
             for (uint32_t k = 0; k < wave; ++k) dst += s_wave_live[k];
-            stream_store(&a.next.origin[dst], no);
-            stream_store(&a.next.direction[dst], nd);
-            stream_store(&a.next.throughput[dst], thr);
-            stream_store(&a.next.rng[dst], make_uint2(static_cast<uint32_t>(rng), static_cast<uint32_t>(rng >> 32)));
-            stream_store(&a.next.slot[dst], slot);
-            float ht;
-            uint32_t hid;
-            seed_hit(a.scene, no, nd, ht, hid, a.test_counters);
-            stream_store(&a.next.hit_t[dst], ht);
-            stream_store(&a.next.hit_id[dst], hid);
+            store_survivor(a.scene, a.next, dst, no, nd, thr, rng, slot, a.test_counters);
         }
         __syncthreads();  // s_wave_live / s_block_base are rewritten next round
     }
     // one atomic per wave for the hit counter
     for (int off = 32; off > 0; off >>= 1) my_hits += __shfl_down(my_hits, off);
     if (lane == 0 && my_hits) atomicAdd(a.hits, my_hits);
+}
+
+// ------------------------------------------------------- the whole bounce loop
+//
+// One launch for all bounces of a batch of paths: every wave owns a contiguous
+// block of the batch's paths and takes it through the bounce loop of
+// lib.rs:313-373 by itself — trace_loop over its block's rays, then shade_entry
+// over the same entries 64 at a time with the survivors written, packed, to the
+// same block of the other queue, and so on until no path of the block is alive.
+// Waves never wait for each other: there is no launch per bounce, no queue
+// counter, no compaction atomic, and on every SIMD some waves traverse (bound by
+// instruction issue) while others shade (bound by memory), with all of the
+// SIMD's wave slots open to both.  Each path goes through exactly the operations
+// of the launch-per-bounce loop, so the results are the same bits.
+//
+// For scenes whose only traversed family is the triangles (spheres and planes
+// absent or scanned where rays are created).  Dynamic LDS: the traversal
+// kernel's layout, then 256 floats (byte / 255).
+// What the shading half of k_path needs, kept in device memory rather than in the kernel's
+// argument block: arguments are fetched into scalar registers at the kernel's entry and would
+// stay there across the traversal loop, which has none to spare.
+struct PathConsts {
+    DScene scene;
+    DQueue q[2];   // [0] holds the batch's camera rays on entry
+    float4* result;
+    unsigned long long* hits;      // segments that hit something
+    unsigned long long* segments;  // rays traced
+};
+
+// (address space 4: memory no kernel writes, so that a wave-uniform read is a scalar load)
+typedef const __attribute__((address_space(4))) PathConsts* PathConstsPtr;
+
+struct PathArgs {
+    TraceArgs t;   // family, tuning and stack overflow area of the traversal (its queue and cursor fields are unused)
+    PathConstsPtr consts;
+    uint32_t n_paths;
+    uint32_t per_wave;     // queue entries set aside for a wave's paths (a multiple of 64)
+    uint32_t max_bounces;
+    uint32_t group;        // paths a wave takes through all bounces before it starts on the next ones (a multiple of 64)
+};
+
+// A copy of a plain struct that lies in that address space (word by word: class types cannot be
+// copied across address spaces by assignment); fields that are not used cost nothing.
+template <class T>
+__device__ __forceinline__ T read_const(const __attribute__((address_space(4))) T* p) {
+    static_assert(sizeof(T) % 4 == 0, "whole words");
+    T out;
+    const __attribute__((address_space(4))) uint32_t* w = (const __attribute__((address_space(4))) uint32_t*)p;
+    uint32_t* o = reinterpret_cast<uint32_t*>(&out);
+#pragma unroll
+    for (size_t k = 0; k < sizeof(T) / 4; ++k) o[k] = w[k];
+    return out;
+}
+
+// (the compiler may not move loads through `p` above this point)
+__device__ __forceinline__ PathConstsPtr fetched_here(PathConstsPtr p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+template <int WAVES, bool FASTSLAB>
+__global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8))) k_path(PathArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    float4* const s_nodes = reinterpret_cast<float4*>(s_raw);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned char* const s_wave = s_raw + static_cast<size_t>(a.t.cache_nodes) * sizeof(DNode) + wave * trace_lds_per_wave(a.t.lds_slots);
+    uint2* const s_stack = reinterpret_cast<uint2*>(s_wave);
+    unsigned long long* const s_res = reinterpret_cast<unsigned long long*>(s_stack + a.t.lds_slots * kTraceBlock);
+    uint32_t* const s_mark = reinterpret_cast<uint32_t*>(s_res + kTraceBlock);
+    const uint32_t gtid = blockIdx.x * (kTraceBlock * WAVES) + threadIdx.x;
+    const uint32_t cache_nodes = a.t.cache_nodes;
+    {
+        float* const s_unit = reinterpret_cast<float*>(s_raw + static_cast<size_t>(cache_nodes) * sizeof(DNode) +
+                                                       WAVES * trace_lds_per_wave(a.t.lds_slots));
+        const float4* src = reinterpret_cast<const float4*>(a.t.fam.nodes);
+        for (uint32_t k = threadIdx.x; k < cache_nodes * 4u; k += kTraceBlock * WAVES)
+            s_nodes[(k & 3u) * cache_nodes + (k >> 2)] = src[k];
+        for (uint32_t k = threadIdx.x; k < 256u; k += kTraceBlock * WAVES) s_unit[k] = static_cast<float>(k) / 255.0f;
+        __syncthreads();
+    }
+    // this wave's paths: blocks g, g + W, g + 2W, ... of the batch's blocks of 64 (see k_raygen), stored from
+    // entry g * per_wave on; only the batch's last block can be short
+    const uint32_t g = blockIdx.x * WAVES + wave, n_waves = gridDim.x * WAVES;
+    const uint32_t n_blocks = (a.n_paths + 63u) >> 6;
+    const uint32_t first = g * a.per_wave;
+    uint32_t n = g < n_blocks ? ((n_blocks - 1u - g) / n_waves + 1u) * 64u : 0u;
+    if (n && g == (n_blocks - 1u) % n_waves && (a.n_paths & 63u)) n -= 64u - (a.n_paths & 63u);
+    // The wave's paths go through the bounce loop in groups: a group is traversed and shaded bounce
+    // after bounce until none of its paths is alive, then the next group starts.  Waves would
+    // otherwise all traverse and all shade at the same times (they have the same amount of work),
+    // and traversal and shading would not overlap on a SIMD; with groups, and first groups of
+    // different sizes from wave to wave, the waves' phases are spread evenly.
+    unsigned long long my_hits = 0, my_segments = 0;
+    const uint32_t n_wave = n;
+    uint32_t group = max(64u, (a.group * (1u + (g * 5u) % 8u) / 8u) & ~63u);  // the first group: 1/8 .. 8/8 of a group
+    for (uint32_t done = 0; done < n_wave; done += group, group = a.group) {
+        n = min(group, n_wave - done);
+        const uint32_t at = first + done;  // the group's entries, in both queues
+        uint32_t c = 0;
+        for (uint32_t b = 0; b < a.max_bounces && n > 0; ++b) {
+            {
+                PathConstsPtr pc = fetched_here(a.consts);
+                DQueue cur{};  // the four arrays the traversal touches
+                cur.origin = pc->q[c].origin;
+                cur.direction = pc->q[c].direction;
+                cur.hit_t = pc->q[c].hit_t;
+                cur.hit_id = pc->q[c].hit_id;
+                trace_loop<2, false, true, WAVES, FASTSLAB>(a.t, cur, s_nodes, s_stack, s_res, s_mark, lane, gtid, cache_nodes, at + n, 64u, at,
+                                                            at + n, true);
+            }
+            if (lane == 0) my_segments += n;
+            PathConstsPtr pc = fetched_here(a.consts);
+            const DScene scene = read_const(&pc->scene);
+            const DQueue cur = read_const(&pc->q[c]), next = read_const(&pc->q[c ^ 1u]);
+            float4* const result = pc->result;
+            const float* s_unit = reinterpret_cast<const float*>(s_raw + static_cast<size_t>(cache_nodes) * sizeof(DNode) +
+                                                                 WAVES * trace_lds_per_wave(a.t.lds_slots));
+            const int last_bounce = b + 1 == a.max_bounces;
+            uint32_t n_out = 0;
+            for (uint32_t blk = 0; blk < n; blk += kTraceBlock) {
+                const uint32_t i = blk + lane;
+                F3 no = f3(0, 0, 0), nd = f3(0, 0, 0), thr = f3(0, 0, 0);
+                unsigned long long rng = 0;
+                uint32_t slot = 0;
+                const bool alive = i < n && shade_entry(scene, cur, at + i, result, last_bounce, s_unit, no, nd, thr, rng, slot, my_hits);
+                const unsigned long long live = __ballot(alive);
+                if (alive) store_survivor(scene, next, at + n_out + bits_below_lane(live), no, nd, thr, rng, slot, nullptr);
+                n_out += __popcll(live);
+            }
+            n = n_out;
+            c ^= 1u;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) my_hits += __shfl_down(my_hits, off);
+    PathConstsPtr pc = fetched_here(a.consts);
+    if (lane == 0 && my_hits) atomicAdd(pc->hits, my_hits);
+    if (lane == 0 && my_segments) atomicAdd(pc->segments, my_segments);
 }
 
 // ------------------------------------------------------------ accumulation

@@ -100,6 +100,7 @@ struct RtContext {
     unsigned long long* d_stats = nullptr;  // hits, then {branch visits, shape tests} per family, then
                                             // {sphere tests, plane tests} of inlined families
     unsigned long long* d_inline_tests = nullptr;  // = d_stats + 7
+    PathConsts* d_path_consts = nullptr;           // argument block of k_path's shading half
     uint32_t* h_pinned = nullptr;           // small pinned read-back area
     size_t h_pinned_words = 0;
 
@@ -125,6 +126,8 @@ struct RtContext {
     uint32_t tune_cache_nodes = 144;  // branch records each multi-wave workgroup copies to LDS
     bool tune_share = true;  // deal pending (ray, triangle) pairs out to all lanes
     bool opt_count = false, opt_time = false, opt_fast_slab = false;
+    uint32_t tune_path_group = 16384;  // paths a wave of k_path takes through all bounces at a time
+    uint32_t opt_fused = 2;  // the whole bounce loop in one launch (k_path): 0 never, 1 whenever the scene allows, 2 for batches below kFusedBelowPaths
     bool debug_tallies = std::getenv("RT_MI355_DEBUG_TALLIES") != nullptr;  // slow diagnostics of the counting kernels
     uint64_t opt_samples_in_flight = 0;  // 0 = automatic
     std::vector<hipEvent_t> events;      // pairs around timed launches
@@ -136,7 +139,9 @@ struct RtContext {
 
 namespace {
 
-constexpr size_t kStatWords = 47;  // + 38 diagnostic tallies of the triangle traversal
+constexpr size_t kStatWords = 48;  // + 38 diagnostic tallies of the triangle traversal + rays traced by k_path
+constexpr size_t kStatSegments = 47;
+constexpr uint32_t kFusedBelowPaths = 3u << 22;  // batch size below which the one-launch bounce loop is the faster one
 
 int fail(RtContext* ctx, int code, const std::string& msg) {
     if (ctx) ctx->error = msg;
@@ -348,9 +353,10 @@ int ensure_workspace(RtContext* ctx, size_t n_paths, size_t n_pixels, size_t n_b
         (void)hipFree(w.result);
         w.result = nullptr;
         w.cap_paths = 0;
-        int rc = alloc_queue(ctx, w.q[0], n_paths);
+        // (entries beyond the paths: k_path stores every wave's share from a multiple of 64 on)
+        int rc = alloc_queue(ctx, w.q[0], n_paths + ctx->max_grid_threads);
         if (rc) return rc;
-        rc = alloc_queue(ctx, w.q[1], n_paths);
+        rc = alloc_queue(ctx, w.q[1], n_paths + ctx->max_grid_threads);
         if (rc) return rc;
         HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&w.result), n_paths * sizeof(float4)));
         w.cap_paths = n_paths;
@@ -572,6 +578,7 @@ int harvest(RtContext* ctx) {
     ctx->stats.prim_tests[0] += h[7];
     ctx->stats.prim_tests[1] += h[8];
     for (int k = 0; k < 38; ++k) ctx->tallies[k] += h[9 + k];
+    ctx->stats.segments += h[kStatSegments];
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof h, ctx->stream));
     return RT_OK;
 }
@@ -594,6 +601,110 @@ size_t choose_samples_in_flight(const RtContext* ctx, size_t n_pixels, uint32_t 
 int render_batch_overlapped(RtContext* ctx, const FrameArgs& f, const DScene& sc, uint32_t B, uint32_t n_paths,
                             uint32_t n_pix, unsigned long long first_sample, uint64_t* segments_out);
 
+// Can the whole bounce loop run as one launch of k_path?  Only the triangle family may need a
+// traversal of its own: spheres and planes must be absent or scanned where rays are created.
+bool fused_loop_possible(const RtContext* ctx) {
+    if (ctx->opt_count || !ctx->tune_share || (ctx->tune_waves != 8 && ctx->tune_waves != 16)) return false;
+    if (ctx->fam[RT_SHAPE_TRIANGLE].n_shapes == 0) return false;
+    for (int kind = 0; kind < 2; ++kind)
+        if (ctx->fam[kind].n_shapes != 0 && ctx->inline_count[kind] == 0) return false;
+    return true;
+}
+
+template <int WAVES, bool FASTSLAB>
+int launch_path_variant(RtContext* ctx, PathArgs a, const FrameArgs& f, uint32_t n_pix, unsigned long long first_sample) {
+    const void* fn = reinterpret_cast<const void*>(&k_path<WAVES, FASTSLAB>);
+    const int block = kTraceBlock * WAVES;
+    a.t.cache_nodes = std::min(ctx->tune_cache_nodes, ctx->fam[RT_SHAPE_TRIANGLE].n_branches);
+    const size_t lds = static_cast<size_t>(a.t.cache_nodes) * sizeof(DNode) + WAVES * trace_lds_per_wave(a.t.lds_slots) + 256 * sizeof(float);
+    const RtContext::Occupancy* it = nullptr;
+    for (const RtContext::Occupancy& o : ctx->trace_occupancy)
+        if (o.fn == fn && o.lds == lds) it = &o;
+    if (!it) {
+        if (lds > 64 * 1024)
+            HIP_TRY(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        int per_cu = 0;
+        HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, block, lds));
+        if (per_cu < 1) return fail(ctx, RT_ERR_INVALID, "bounce-loop workgroup does not fit a compute unit (waves, LDS slots, cached nodes)");
+        per_cu = std::min(per_cu, 32 / WAVES);
+        RtContext::Occupancy& slot = ctx->trace_occupancy[ctx->trace_occupancy_next++ % 32u];
+        slot = RtContext::Occupancy{fn, lds, per_cu};
+        it = &slot;
+    }
+    uint32_t grid = static_cast<uint32_t>(ctx->n_cus) * static_cast<uint32_t>(it->per_cu);
+    // a small batch: no more waves than blocks of 64 paths
+    const uint32_t blocks_of_64 = (a.n_paths + 63u) / 64u;
+    grid = std::max(1u, std::min(grid, (blocks_of_64 + WAVES - 1) / WAVES));
+    const uint32_t n_waves = grid * WAVES;
+    a.per_wave = ((blocks_of_64 + n_waves - 1) / n_waves) * 64u;
+    a.t.spill_stride = grid * static_cast<uint32_t>(block);
+    if (a.t.spill_stride > ctx->max_grid_threads) return fail(ctx, RT_ERR_INVALID, "bounce-loop grid larger than the stack overflow area");
+    if (static_cast<uint64_t>(a.per_wave) * n_waves > ctx->ws.cap_paths + ctx->max_grid_threads) return fail(ctx, RT_ERR_INVALID, "path queues too short for the waves' blocks");
+    if (ctx->debug_tallies)
+        std::fprintf(stderr, "[rt_mi355] bounce loop: %u workgroups of %d waves (%d per CU), %zu bytes of LDS, %u paths per wave\n", grid,
+                     WAVES, it->per_cu, lds, a.per_wave);
+    // camera rays, dealt out to the waves in blocks of 64
+    hipLaunchKernelGGL(k_raygen, dim3((a.n_paths + 255) / 256), dim3(256), 0, ctx->stream, f, device_scene(ctx), ctx->ws.q[0], 0u, a.n_paths, n_pix,
+                       first_sample, 1, ctx->ws.counters, inline_counters(ctx), n_waves, a.per_wave);
+    HIP_TRY(ctx, hipGetLastError());
+    if (ctx->opt_time) HIP_TRY(ctx, hipEventRecord(ctx->events[ctx->events_used], ctx->stream));
+    hipLaunchKernelGGL((k_path<WAVES, FASTSLAB>), dim3(grid), dim3(block), lds, ctx->stream, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+// One batch of the bounce loop as a single launch (k_path).
+int render_batch_fused(RtContext* ctx, const FrameArgs& f, const DScene& sc, uint32_t B, uint32_t n_paths, uint32_t n_pix,
+                       unsigned long long first_sample) {
+    Workspace& w = ctx->ws;
+    HIP_TRY(ctx, hipMemsetAsync(w.counters, 0, 4 * sizeof(uint32_t), ctx->stream));
+    PathArgs a{};
+    a.t.fam = sc.family[RT_SHAPE_TRIANGLE];
+    a.t.spill = ctx->ws.spill;
+    a.t.lds_slots = ctx->tune_lds_slots;
+    a.t.phase_min = ctx->tune_phase_min;
+    a.t.chunk_max = ctx->tune_chunk_max;
+    a.t.pair_min = ctx->tune_pair_min;
+    a.t.refill_min = ctx->tune_refill_min;
+    a.t.bounds_fast = ctx->fam[RT_SHAPE_TRIANGLE].bounds_fast ? 1 : 0;
+    if (!ctx->d_path_consts) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_path_consts), sizeof(PathConsts)));
+    PathConsts pc{};
+    pc.scene = sc;
+    pc.q[0] = w.q[0];
+    pc.q[1] = w.q[1];
+    pc.result = w.result;
+    pc.hits = ctx->d_stats;
+    pc.segments = ctx->d_stats + kStatSegments;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_path_consts, &pc, sizeof pc, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // `pc` leaves scope
+    a.consts = (PathConstsPtr)ctx->d_path_consts;
+    a.group = ctx->tune_path_group;
+    a.n_paths = n_paths;
+    a.max_bounces = B;
+    if (ctx->opt_time) {
+        while (ctx->events_used + 2 > ctx->events.size()) {
+            hipEvent_t ev;
+            HIP_TRY(ctx, hipEventCreate(&ev));
+            ctx->events.push_back(ev);
+        }
+    }
+    int rc;
+    if (ctx->opt_fast_slab)
+        rc = ctx->tune_waves == 16 ? launch_path_variant<16, true>(ctx, a, f, n_pix, first_sample)
+                                   : launch_path_variant<8, true>(ctx, a, f, n_pix, first_sample);
+    else
+        rc = ctx->tune_waves == 16 ? launch_path_variant<16, false>(ctx, a, f, n_pix, first_sample)
+                                   : launch_path_variant<8, false>(ctx, a, f, n_pix, first_sample);
+    if (rc) return rc;
+    if (ctx->opt_time) {
+        HIP_TRY(ctx, hipEventRecord(ctx->events[ctx->events_used + 1], ctx->stream));
+        ctx->events_used += 2;
+        ctx->stats.trace_launches++;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return harvest(ctx);
+}
+
 // One batch of the bounce loop: samples [first_sample, first_sample + nb) of every pixel
 // of the region, each path's final radiance left in the workspace's result array
 // ([sample in batch][pixel]).  The workspace must hold nb * n_pixels paths.
@@ -607,6 +718,11 @@ int trace_batch(RtContext* ctx, const FrameArgs& f, const DScene& sc, uint32_t B
     const uint32_t n_paths = nb * n_pix;
     int rc = RT_OK;
     ctx->stats.paths += n_paths;
+    // Batches below about 12 M paths run as one launch (k_path): 3.8x faster at 65 k paths, 2x at 2 M (one sample
+    // of a 1080p frame), equal at 16 M.  Larger ones are faster launch by launch: shading needs far more
+    // memory requests in flight than the few waves that shade at any moment inside k_path can have.
+    if (B > 0 && fused_loop_possible(ctx) && (ctx->opt_fused == 1 || (ctx->opt_fused == 2 && n_paths < kFusedBelowPaths)))
+        return render_batch_fused(ctx, f, sc, B, n_paths, n_pix, first_sample);
     // large batches run as two overlapped half-batches (not while counting: the counting kernels are slow anyway)
     const bool overlapped = ctx->n_chains > 1 && !ctx->opt_count && B > 0 && n_paths >= (1u << 21);
     if (overlapped) {
@@ -965,6 +1081,7 @@ void rt_destroy(RtContext* ctx) {
     for (int h = 1; h < kMaxChains; ++h)
         if (ctx->chain_stream[h]) (void)hipStreamDestroy(ctx->chain_stream[h]);
     (void)hipFree(ctx->d_stats);
+    (void)hipFree(ctx->d_path_consts);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1022,6 +1139,14 @@ int rt_set_option(RtContext* ctx, uint32_t option, uint64_t value) {
         case RT_OPT_TRACE_CHUNK:
             if (value < 64 || value > 4096 || value % 64) return fail(ctx, RT_ERR_INVALID, "chunk must be a multiple of 64 in 64..4096");
             ctx->tune_chunk_max = static_cast<uint32_t>(value);
+            return RT_OK;
+        case RT_OPT_PATH_GROUP:
+            if (value < 64 || value > (1u << 24) || value % 64) return fail(ctx, RT_ERR_INVALID, "path group must be a multiple of 64 in 64..2^24");
+            ctx->tune_path_group = static_cast<uint32_t>(value);
+            return RT_OK;
+        case RT_OPT_FUSED_LOOP:
+            if (value > 2) return fail(ctx, RT_ERR_INVALID, "fused bounce loop: 0 (never), 1 (whenever possible) or 2 (for small batches)");
+            ctx->opt_fused = static_cast<uint32_t>(value);
             return RT_OK;
         default: return fail(ctx, RT_ERR_INVALID, "unknown option");
     }

@@ -153,12 +153,18 @@ def test_deep_tree_full_frame_contains_oracle_tiles(renderer, tree):
         cpu_hits = O.trace_primary(tree, p, 0, True)
         band = gpu_hits[y0:y0 + 48, x0:x0 + 64]
         assert np.array_equal(band["prim"], cpu_hits["prim"]) and np.array_equal(bits(band["t"]), bits(cpu_hits["t"]))
-    # enough paths for two chains (deep stacks: each chain's overflow area is in heavy use)
-    renderer.set_option(F.RT_OPT_CHAINS, 1)
-    one = renderer.render_sums(tree.params, 2, 12)
-    renderer.set_option(F.RT_OPT_CHAINS, 2)
-    two = renderer.render_sums(tree.params, 2, 12)
-    assert np.array_equal(bits(one), bits(two))
+    # enough paths for two chains (deep stacks: each chain's overflow area is in heavy use); a batch
+    # of this size would otherwise take the one-launch loop, which is compared with both
+    fused = renderer.render_sums(tree.params, 2, 12)
+    renderer.set_option(F.RT_OPT_FUSED_LOOP, 0)
+    try:
+        renderer.set_option(F.RT_OPT_CHAINS, 1)
+        one = renderer.render_sums(tree.params, 2, 12)
+        renderer.set_option(F.RT_OPT_CHAINS, 2)
+        two = renderer.render_sums(tree.params, 2, 12)
+    finally:
+        renderer.set_option(F.RT_OPT_FUSED_LOOP, 2)
+    assert np.array_equal(bits(one), bits(two)) and np.array_equal(bits(one), bits(fused))
 
 
 # ---------------------------------------------------------------- 16K x 16K image

@@ -52,6 +52,13 @@ def check_scene(renderer, scene, spp=None, traversal_counters=True):
     cpu_img, _ = O.render(scene, p, threads=4)
     gpu_img = renderer.render(p)
     assert np.array_equal(gpu_img, cpu_img)
+    # a frame this small takes the one-launch bounce loop where the scene allows it; the
+    # launch-per-bounce loop (what large batches use) must store the same bytes
+    renderer.set_option(F.RT_OPT_FUSED_LOOP, 0)
+    try:
+        assert np.array_equal(renderer.render(p), cpu_img)
+    finally:
+        renderer.set_option(F.RT_OPT_FUSED_LOOP, 2)
     return gpu
 
 
