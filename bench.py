@@ -451,6 +451,16 @@ def main() -> None:
                 "traffic_frac_of_hbm_peak": None,
                 "profile": {"file": os.path.relpath(PROFILE, ROOT), "source_hash": kernel_source_hash()},
             })
+            # The same against what this kernel's own instruction mix can issue: its packed, min/max, compare
+            # and select instructions hold a SIMD's issue for about twice as long as a plain FP32 one
+            # (profiles/r01_valu_issue_costs.txt); the counter record has the cycles the vector ALUs were busy
+            # per instruction of the kernel (SQ_ACTIVE_INST_VALU x 4 / SQ_INSTS_VALU).
+            cpi = rec["trace"].get("valu_cycles_per_inst")
+            if cpi:
+                mix_peak = 1024 * 2.4 / cpi
+                roofline["issue_cycles_per_inst_of_this_mix"] = cpi
+                roofline["frac_at_this_mix"] = round(per_launch / mix_peak, 5)
+                roofline["frac_all_launches_over_wall_at_this_mix"] = round(over_wall / mix_peak, 5)
             if rec["trace"].get("hbm_bytes_per_ray") is not None:
                 traffic = rec["trace"]["hbm_bytes_per_ray"] * rays_per_launch
                 roofline["traffic"] = round(traffic)
