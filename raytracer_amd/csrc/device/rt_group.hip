@@ -135,6 +135,9 @@ int check_group(RtGroup* g, const RtRenderParams* p) {
     if (!g) return RT_ERR_INVALID;
     if (!p) return group_fail(g, RT_ERR_INVALID, "null render parameters");
     if (p->width < 2 || p->height < 2) return group_fail(g, RT_ERR_INVALID, "width and height must be at least 2");
+    if ((p->tile_w != 0) != (p->tile_h != 0) || static_cast<uint64_t>(p->tile_x) + p->tile_w > p->width ||
+        static_cast<uint64_t>(p->tile_y) + p->tile_h > p->height)
+        return group_fail(g, RT_ERR_INVALID, "tile outside the frame");
     return ensure_sums(g, pixels_of(p));
 }
 
