@@ -44,13 +44,13 @@ PROFILE = os.path.join(ROOT, "profiles", "r02_counters.json")
 
 def kernel_source_hash() -> str:
     """Identifies the device code a counter profile belongs to: a hash over the
-    kernel sources and the build flags (the Makefile)."""
-    import glob
+    sources of the render loop's kernels and of their launches, and the build flags
+    (the Makefile)."""
     import hashlib
 
     h = hashlib.sha256()
     base = os.path.join(ROOT, "raytracer_amd", "csrc")
-    for path in sorted(glob.glob(os.path.join(base, "device", "*")) + [os.path.join(base, "Makefile")]):
+    for path in [os.path.join(base, "device", n) for n in ("kernels.h", "layout.h", "rt_context.hip")] + [os.path.join(base, "Makefile")]:
         with open(path, "rb") as f:
             h.update(os.path.basename(path).encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
