@@ -400,6 +400,12 @@ def main() -> None:
         algorithmic_gbs = trace_bytes_per_ray * my_segments / (my_trace_ms / 1e3) / 1e9 if my_trace_ms > 0 else 0.0
         rays_per_s = segments / dt
         rec = recorded_counters(args)
+        # batches below 3 * 2^22 paths run as one launch of k_path (the library's own rule); the counter
+        # record describes k_trace, so no fraction is quoted for such a run
+        pixels = (params.tile_w * params.tile_h) if params.tile_w else params.width * params.height
+        one_launch = not tiled and pixels * min(args.spp, max(1, (1 << 28) // pixels)) < (3 << 22)
+        if one_launch:
+            rec = None
         # The traversal kernel's working set (branch records, triangles) lives in LDS, L2 and the
         # Infinity Cache, so HBM does not bound it; vector-instruction issue does.  Roof: every SIMD
         # issuing one wave64 vector instruction per 2 cycles at 2.4 GHz.  Instructions per ray come from
@@ -407,7 +413,7 @@ def main() -> None:
         # the rays of the launch); without a matching record the figures are null.
         roofline = {
             "bound": "valu_issue",
-            "kernel": "k_trace<TRIANGLE>",
+            "kernel": "k_path (whole bounce loop, one launch per batch)" if one_launch else "k_trace<TRIANGLE>",
             "unit": "G wave-instr/s",
             "peak": VALU_PEAK_GINSTR,
             "achieved": None, "frac": None, "traffic": None,

@@ -930,6 +930,11 @@ __device__ __forceinline__ bool shade_entry(const DScene& scene, const DQueue& c
     thr = stream_load(&cur.throughput[i]);
     slot = stream_load(&cur.slot[i]);
     const uint32_t id = stream_load(&cur.hit_id[i]);
+    // (the generator state and the distance are only needed after a hit, but fetched with the rest of the
+    // entry: a load that waited for the id would be one more trip to memory for nearly every path)
+    uint2 rs = stream_load(&cur.rng[i]);
+    float t = stream_load(&cur.hit_t[i]);
+    asm volatile("" : "+v"(rs.x), "+v"(rs.y), "+v"(t));  // (keeps these loads above the test of `id`)
     if (id == kHitNone) {
         // lib.rs:337-345
         const float s = 0.5f * (d.y + 1.0f);
@@ -938,9 +943,7 @@ __device__ __forceinline__ bool shade_entry(const DScene& scene, const DQueue& c
         in_global(result)[slot] = make_float4(thr.x, thr.y, thr.z, 0.0f);
     } else {
         ++hits;
-        const uint2 rs = stream_load(&cur.rng[i]);
         rng = (static_cast<unsigned long long>(rs.y) << 32) | rs.x;
-        const float t = stream_load(&cur.hit_t[i]);
         const uint32_t kind = id >> kHitKindShift, prim = id & kHitPrimMask;
         const F3 p = o + d * t;  // bvh.rs:303
         F3 normal;
