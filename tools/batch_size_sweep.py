@@ -1,3 +1,10 @@
+#!/usr/bin/env python3
+"""Render time by batch size for the two bounce loops (one launch per batch, RT_OPT_FUSED_LOOP = 1,
+against one launch per bounce, = 0) on the bench scene: a 256 x 256 window and the whole 1080p
+frame at 1 .. 32 samples per pixel, best of three.  profiles/r02_fused_loop.txt is its output.
+
+  python tools/batch_size_sweep.py
+"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import argparse
