@@ -291,6 +291,11 @@ def main() -> None:
             dist.recv(t, src)
         torch.cuda.synchronize()
 
+    def agree_min(n):
+        t = torch.tensor([n], dtype=torch.int64, device="cpu" if args.rehearse_on_one_gpu else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item())
+
     step_no = [0]
     if args.workload == "room16k":
         # tiles dealt to the ranks, every rank writing its tiles into the one mapped file:
@@ -312,7 +317,7 @@ def main() -> None:
     else:
         def step():
             if args.exact and world > 1:
-                sums = render_pass_exact(backend, 0, args.spp, world, rank, send_sums, recv_sums)
+                sums = render_pass_exact(backend, 0, args.spp, world, rank, send_sums, recv_sums, agree_min=agree_min)
             else:
                 sums = render_pass(backend, 0, args.spp, world, rank, reduce_to_root)
             if rank == 0:

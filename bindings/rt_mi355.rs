@@ -83,6 +83,9 @@ unsafe extern "C" {
         ctx: *mut RtContext, params: *const RtRenderParams, sample_begin: u32, sample_count: u32,
         traced: *mut u32,
     ) -> c_int;
+    pub fn rt_reserve_samples(
+        ctx: *mut RtContext, params: *const RtRenderParams, sample_count: u32, in_flight: *mut u32,
+    ) -> c_int;
     pub fn rt_fold_samples(
         ctx: *mut RtContext, params: *const RtRenderParams, carry_on: c_int, sums: *mut f32,
         sums_on_device: c_int,

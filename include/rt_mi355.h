@@ -318,6 +318,14 @@ int rt_trace_samples(RtContext* ctx, const RtRenderParams* params,
                      uint32_t sample_begin, uint32_t sample_count, uint32_t* traced);
 int rt_fold_samples(RtContext* ctx, const RtRenderParams* params, int carry_on,
                     float* sums, int sums_on_device);
+/* Sizes the context's device workspace for up to `sample_count` samples of the
+ * region in flight and reports in `*in_flight` how many one rt_trace_samples
+ * call will then take (fewer than asked when the memory or RT_OPT_SAMPLES_IN_FLIGHT
+ * says so).  A driver of several GPUs asks every GPU first and then hands out
+ * pieces that all of them trace in one call, so that they stay in step.  The
+ * same allocation happens inside the render and trace calls when they need it. */
+int rt_reserve_samples(RtContext* ctx, const RtRenderParams* params, uint32_t sample_count,
+                       uint32_t* in_flight);
 
 /* Mean, gamma and quantisation of :283-295: rgb8 = u8(sqrt(sums/n)*255), or
  * with `running_average` the blend with the bytes already in `rgb8` weighted

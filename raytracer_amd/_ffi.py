@@ -111,6 +111,7 @@ _DEVICE_SYMBOLS = {
     "rt_render_sums": (C.c_int, [C.c_void_p, C.POINTER(RtRenderParams), u32, u32, C.c_void_p, C.c_int]),
     "rt_render_sums_onto": (C.c_int, [C.c_void_p, C.POINTER(RtRenderParams), u32, u32, C.c_void_p, C.c_int]),
     "rt_trace_samples": (C.c_int, [C.c_void_p, C.POINTER(RtRenderParams), u32, u32, C.POINTER(u32)]),
+    "rt_reserve_samples": (C.c_int, [C.c_void_p, C.POINTER(RtRenderParams), u32, C.POINTER(u32)]),
     "rt_fold_samples": (C.c_int, [C.c_void_p, C.POINTER(RtRenderParams), C.c_int, C.c_void_p, C.c_int]),
     "rt_resolve": (C.c_int, [C.c_void_p, C.POINTER(RtRenderParams), C.c_void_p, C.c_int, u32, C.c_int,
                              u32, C.c_void_p]),

@@ -1403,6 +1403,20 @@ int rt_trace_samples(RtContext* ctx, const RtRenderParams* p, uint32_t sample_be
     return RT_OK;
 }
 
+int rt_reserve_samples(RtContext* ctx, const RtRenderParams* p, uint32_t sample_count, uint32_t* in_flight) {
+    int rc = require_scene(ctx);
+    if (rc) return rc;
+    Region r;
+    rc = check_params(ctx, p, r);
+    if (rc) return rc;
+    if (!in_flight || sample_count == 0) return fail(ctx, RT_ERR_INVALID, "bad arguments");
+    size_t S = 0;
+    rc = workspace_for_samples(ctx, r, sample_count, p->max_bounces, &S);
+    if (rc) return rc;
+    *in_flight = std::min<uint32_t>(static_cast<uint32_t>(S), sample_count);
+    return RT_OK;
+}
+
 int rt_fold_samples(RtContext* ctx, const RtRenderParams* p, int carry_on, float* sums, int sums_on_device) {
     if (!ctx) return RT_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));

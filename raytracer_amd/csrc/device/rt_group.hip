@@ -4,7 +4,7 @@
 // with a list of GPUs gets the image one GPU would store, bit for bit.
 //
 // The scene is replicated (one context per listed GPU).  A pass's samples are
-// split into contiguous shares, every member traces its share at the same time
+// dealt out in contiguous pieces, every member traces its piece at the same time
 // on a host thread of its own (rt_trace_samples: per-sample radiance stays on
 // the member's GPU), then the running per-pixel sums travel from member to
 // member in sample order (hipMemcpyPeer) and each member folds its samples onto
@@ -75,57 +75,68 @@ size_t pixels_of(const RtRenderParams* p) {
     return p->tile_w ? static_cast<size_t>(p->tile_w) * p->tile_h : static_cast<size_t>(p->width) * p->height;
 }
 
-// Member k's share of `count` samples: contiguous, earlier members take the larger shares.
-void share_of(uint32_t count, size_t n, size_t k, uint32_t* first, uint32_t* mine) {
-    const uint32_t base = count / static_cast<uint32_t>(n), extra = count % static_cast<uint32_t>(n);
-    *mine = base + (k < extra ? 1u : 0u);
-    *first = base * static_cast<uint32_t>(k) + static_cast<uint32_t>(std::min<size_t>(k, extra));
-}
-
 // Samples [begin, begin + count) of every pixel folded onto the sums of the samples before
 // them (`carry_on`: member 0's buffer holds those; otherwise the fold starts empty).  On
 // return the buffer of the last member that had samples holds the result; its index is
 // returned in *holder.
+//
+// The samples are taken in rounds of one piece per member — member k the k-th piece of the
+// round, all pieces traced at the same time, then folded in member order — with pieces no
+// larger than the smallest number of samples any member holds in flight, so that no GPU
+// waits while another works through a share that did not fit at once.
 int group_sums(RtGroup* g, const RtRenderParams* p, uint32_t begin, uint32_t count, bool carry_on, size_t* holder) {
-    const size_t n = g->member.size();
+    const uint32_t n = static_cast<uint32_t>(g->member.size());
     const size_t bytes = pixels_of(p) * 3 * sizeof(float);
-    std::vector<uint32_t> first(n), mine(n), traced(n, 0);
-    std::vector<int> rc(n, RT_OK);
-    for (size_t k = 0; k < n; ++k) share_of(count, n, k, &first[k], &mine[k]);
-    // every member traces (the first piece of) its share at the same time
+    uint32_t fit = (count + n - 1) / n;  // the whole pass in one round, if it fits
     {
-        std::vector<std::thread> workers;
-        for (size_t k = 1; k < n; ++k)
-            if (mine[k])
-                workers.emplace_back([&, k] { rc[k] = rt_trace_samples(g->member[k], p, begin + first[k], mine[k], &traced[k]); });
-        if (mine[0]) rc[0] = rt_trace_samples(g->member[0], p, begin + first[0], mine[0], &traced[0]);
-        for (std::thread& t : workers) t.join();
+        const uint32_t want = fit;
+        for (uint32_t k = 0; k < n && k < count; ++k) {
+            uint32_t here = 0;
+            const int rc = rt_reserve_samples(g->member[k], p, want, &here);
+            if (rc != RT_OK) return member_fail(g, k, rc);
+            fit = std::min(fit, here);
+        }
     }
-    for (size_t k = 0; k < n; ++k)
-        if (rc[k] != RT_OK) return member_fail(g, k, rc[k]);
-    // the sums go from member to member in sample order
+    std::vector<uint32_t> first(n), mine(n), traced(n);
+    std::vector<int> rc(n);
     size_t last = 0;
     bool have = carry_on;  // does some buffer hold the fold so far?
-    for (size_t k = 0; k < n; ++k) {
-        if (!mine[k]) continue;
-        if (have && k != last) {
-            if (hipMemcpyPeer(g->d_sums[k], g->device[k], g->d_sums[last], g->device[last], bytes) != hipSuccess) {
+    for (uint32_t done = 0; done < count;) {
+        const uint32_t left = count - done;
+        const uint32_t piece = std::min(fit, (left + n - 1) / n);
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint64_t at = static_cast<uint64_t>(k) * piece;
+            first[k] = done + static_cast<uint32_t>(std::min<uint64_t>(at, left));
+            mine[k] = at < left ? std::min<uint32_t>(piece, left - static_cast<uint32_t>(at)) : 0u;
+            traced[k] = 0;
+            rc[k] = RT_OK;
+        }
+        {
+            std::vector<std::thread> workers;
+            for (uint32_t k = 1; k < n; ++k)
+                if (mine[k])
+                    workers.emplace_back([&, k] { rc[k] = rt_trace_samples(g->member[k], p, begin + first[k], mine[k], &traced[k]); });
+            rc[0] = rt_trace_samples(g->member[0], p, begin + first[0], mine[0], &traced[0]);  // mine[0] >= 1
+            for (std::thread& t : workers) t.join();
+        }
+        for (uint32_t k = 0; k < n; ++k) {
+            if (rc[k] != RT_OK) return member_fail(g, k, rc[k]);
+            if (traced[k] != mine[k]) return group_fail(g, RT_ERR_STATE, "a member traced fewer samples than it had reserved room for");
+        }
+        // the sums go from member to member in sample order
+        for (uint32_t k = 0; k < n; ++k) {
+            if (!mine[k]) continue;
+            if (have && k != last &&
+                hipMemcpyPeer(g->d_sums[k], g->device[k], g->d_sums[last], g->device[last], bytes) != hipSuccess) {
                 (void)hipGetLastError();
                 return group_fail(g, RT_ERR_HIP, "copy of the sums between GPUs failed");
-            }
-        }
-        uint32_t done = 0;
-        while (done < mine[k]) {
-            if (done) {  // the share did not fit in flight at once: the rest, piece by piece
-                const int r = rt_trace_samples(g->member[k], p, begin + first[k] + done, mine[k] - done, &traced[k]);
-                if (r != RT_OK) return member_fail(g, k, r);
             }
             const int r = rt_fold_samples(g->member[k], p, have ? 1 : 0, g->d_sums[k], 1);
             if (r != RT_OK) return member_fail(g, k, r);
             have = true;
-            done += traced[k];
+            last = k;
+            done += mine[k];
         }
-        last = k;
     }
     *holder = last;
     return RT_OK;

@@ -12,11 +12,11 @@ Every (sample, pixel) has its own generator sub-stream, so the set of samples
 rendered does not depend on G; only the order in which per-rank partial sums
 are added differs from the single-GPU left fold (last-bit float differences).
 
-`render_pass_exact` removes that difference: the ranks trace their shares at the
-same time, then the running sums go from rank to rank in sample order and every
-rank folds its samples onto them, which is the single-GPU sequence of additions.
-The price is a chain of world-1 point-to-point transfers of the sums per pass
-instead of one reduce.
+`render_pass_exact` removes that difference: the ranks trace contiguous pieces of
+the pass at the same time, then the running sums go from rank to rank in sample
+order and every rank folds its samples onto them, which is the single-GPU
+sequence of additions.  The price is a chain of point-to-point transfers of the
+sums (world - 1 per round of pieces) instead of one reduce.
 """
 from __future__ import annotations
 
@@ -56,29 +56,65 @@ def render_pass(backend: SumsBackend, sample_begin: int, sample_count: int, worl
     return sums
 
 
+def fold_in_sample_order(trace, fold, buffer, zeros, reserve, sample_begin: int, sample_count: int, world: int,
+                         rank: int, send: Callable | None, recv: Callable | None, agree_min: Callable | None = None):
+    """The running sums of samples [sample_begin, sample_begin + sample_count) by the single-GPU
+    sequence of additions, over `world` ranks; complete on the last rank.
+
+    The samples are taken in rounds of one contiguous piece per rank (rank k the k-th piece of
+    the round).  In a round every rank traces its piece at once, then the sums go down the
+    ranks in order, each folding its piece onto them; the last rank hands them to rank 0 for
+    the next round.  A rank starts tracing its next piece as soon as it has passed the sums
+    on, so the ranks work side by side however many rounds a pass takes.  A piece is no
+    larger than what the fullest rank holds in flight (`reserve(count)` -> samples one
+    `trace` call takes; `agree_min(n)` -> the minimum of n over the ranks, e.g. an all-reduce
+    with MIN — without it the ranks are taken to be configured alike).
+
+    trace(first, n) -> samples traced; fold(carry_on) -> sums; buffer() -> the tensor to
+    receive into; zeros() -> sums of nothing; send(sums, dst) / recv(sums, src)."""
+    per_rank = -(-sample_count // world)
+    fit = reserve(per_rank) if per_rank else 1
+    if agree_min is not None and world > 1:
+        fit = int(agree_min(fit))
+    if fit < 1:
+        raise RuntimeError("no room for a single sample in flight")
+    sums, done = None, 0
+    while True:
+        left = sample_count - done
+        piece = min(fit, -(-left // world))
+        final = world * piece >= left
+        at = rank * piece
+        mine = max(0, min(piece, left - at))
+        if mine and trace(sample_begin + done + at, mine) != mine:
+            raise RuntimeError("traced fewer samples than reserved room for")
+        carry_on = rank > 0 or done > 0  # someone holds the fold so far: the rank before, or the last rank of the round before
+        if carry_on and world > 1:
+            sums = buffer()
+            recv(sums, rank - 1 if rank > 0 else world - 1)
+        if mine:
+            sums = fold(carry_on)
+        elif not carry_on:
+            sums = zeros()  # no samples at all
+        if rank + 1 < world:
+            send(sums, rank + 1)
+        elif not final and world > 1:
+            send(sums, 0)
+        if final:
+            return sums
+        done += world * piece
+
+
 def render_pass_exact(backend, sample_begin: int, sample_count: int, world: int, rank: int,
-                      send: Callable | None, recv: Callable | None, to_rank0: bool = True):
+                      send: Callable | None, recv: Callable | None, to_rank0: bool = True,
+                      agree_min: Callable | None = None):
     """One pass whose result does not depend on `world`, bit for bit.  Returns the tensor
     of sums, complete on the last rank (world - 1) and, with `to_rank0`, on rank 0.
     `send(tensor, dst)` / `recv(tensor, src)` are `dist.send` / `dist.recv`; None when
-    world == 1.  `backend`: trace(begin, count) -> samples traced, fold(carry_on) ->
-    tensor, zeros(), .buffer (the tensor all of them work on)."""
-    first, mine = sample_share(sample_begin, sample_count, world, rank)
-    # earlier ranks take the larger shares, so a rank with samples has predecessors with samples
-    has_predecessor = rank > 0
-    traced = backend.trace(first, mine) if mine > 0 else 0  # every rank at the same time
-    if rank > 0:
-        recv(backend.buffer, rank - 1)
-    done = 0
-    while done < mine:
-        if done:  # the share did not fit in flight at once: the rest, piece by piece
-            traced = backend.trace(first + done, mine - done)
-        backend.fold(carry_on=has_predecessor or done > 0)
-        done += traced
-    if rank == 0 and mine == 0:
-        backend.zeros()
-    if rank + 1 < world:
-        send(backend.buffer, rank + 1)
+    world == 1.  `backend`: reserve(count) -> samples one trace call takes, trace(begin,
+    count) -> samples traced, fold(carry_on) -> tensor, zeros(), .buffer (the tensor all of
+    them work on).  `agree_min`: see fold_in_sample_order."""
+    fold_in_sample_order(backend.trace, backend.fold, lambda: backend.buffer, backend.zeros, backend.reserve,
+                         sample_begin, sample_count, world, rank, send, recv, agree_min)
     if to_rank0 and world > 1:
         if rank == world - 1:
             send(backend.buffer, 0)
@@ -123,6 +159,9 @@ class GpuSumsBackend:
         self.buffer.zero_()
         self.settle()
         return self.buffer
+
+    def reserve(self, sample_count: int) -> int:
+        return self.renderer.reserve_samples(self.params, sample_count)
 
     def trace(self, sample_begin: int, sample_count: int) -> int:
         return self.renderer.trace_samples(self.params, sample_begin, sample_count)

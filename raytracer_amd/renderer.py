@@ -132,6 +132,13 @@ class Renderer:
         self._check(self._lib.rt_trace_samples(self._ctx, C.byref(params), sample_begin, sample_count, C.byref(traced)))
         return int(traced.value)
 
+    def reserve_samples(self, params, sample_count: int) -> int:
+        """Sizes the device workspace for up to `sample_count` samples of the region in
+        flight and returns how many one trace_samples call will take."""
+        fit = F.u32(0)
+        self._check(self._lib.rt_reserve_samples(self._ctx, C.byref(params), sample_count, C.byref(fit)))
+        return int(fit.value)
+
     def fold_samples(self, params, carry_on: bool, sums, sums_on_device: bool = False):
         """Folds the traced samples, in sample order, onto `sums` (carry_on) or into it
         from nothing.  `sums`: float32 (h, w, 3) array, or a device pointer."""

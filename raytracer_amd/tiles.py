@@ -25,7 +25,7 @@ from typing import Callable, Protocol
 import numpy as np
 
 from . import _ffi as F
-from .distributed import sample_share
+from .distributed import fold_in_sample_order, sample_share
 
 
 class Image:
@@ -113,6 +113,9 @@ class TileBackend(Protocol):
 
     def zeros(self, params): ...
 
+    def reserve(self, params, sample_count: int) -> int:
+        """(exact groups only) Room for up to `sample_count` samples of the tile in flight; returns how many one trace takes."""
+
     def trace(self, params, sample_begin: int, sample_count: int) -> int:
         """(exact groups only) Trace as many of the samples as fit; their radiance waits for fold."""
 
@@ -141,12 +144,13 @@ def render_tiled(backend: TileBackend, image: Image, params, tile_w: int, tile_h
                  progress: Callable | None = None, exact_in_group: tuple[Callable, Callable] | None = None) -> None:
     """Render `params` (full image) into `image`.
 
-    exact_in_group = (send, recv), instead of reduce_in_group: `send(sums, member)` /
-    `recv(sums, member)` move a tile's sums to / from another member of this rank's group
-    (dist.send / dist.recv to the member's rank).  The members then trace their shares of
-    the tile's samples at the same time and fold them in sample order, the sums going from
-    member to member; the group's last member writes the tile, and its bytes are those of a
-    group of one (raytracer_amd.distributed.render_pass_exact, per tile).
+    exact_in_group = (send, recv) or (send, recv, agree_min), instead of reduce_in_group:
+    `send(sums, member)` / `recv(sums, member)` move a tile's sums to / from another member
+    of this rank's group (dist.send / dist.recv to the member's rank).  The members then
+    trace pieces of the tile's samples at the same time and fold them in sample order, the
+    sums going from member to member; the group's last member writes the tile, and its
+    bytes are those of a group of one (raytracer_amd.distributed.fold_in_sample_order, per
+    tile; `agree_min(n)` -> the minimum of n over the group's members).
 
     reduce_in_group(sums): sum over the ranks of this rank's group onto the
     group's first rank (dist.reduce on the group's process group); required when
@@ -175,22 +179,11 @@ def render_tiled(backend: TileBackend, image: Image, params, tile_w: int, tile_h
     image.flush()
 
 
-def _exact_tile_sums(backend, tp, first, n, group_size, member, send, recv):
+def _exact_tile_sums(backend, tp, begin, count, group_size, member, send, recv, agree_min=None):
     """The tile's sums by the hand-over of render_pass_exact; complete on the last member."""
-    traced = backend.trace(tp, first, n) if n > 0 else 0  # every member at the same time
-    sums = backend.zeros(tp) if member == 0 and n == 0 else None
-    if member > 0:
-        sums = backend.sums(tp)
-        recv(sums, member - 1)
-    done = 0
-    while done < n:
-        if done:
-            traced = backend.trace(tp, first + done, n - done)
-        sums = backend.fold(tp, carry_on=member > 0 or done > 0)
-        done += traced
-    if member + 1 < group_size:
-        send(sums, member + 1)
-    return sums
+    return fold_in_sample_order(lambda first, n: backend.trace(tp, first, n), lambda carry_on: backend.fold(tp, carry_on),
+                                lambda: backend.sums(tp), lambda: backend.zeros(tp), lambda n: backend.reserve(tp, n),
+                                begin, count, group_size, member, send, recv, agree_min)
 
 
 def _render_passes(backend, image, params, grid, mine, copier, chunk, n_passes, running, first_pass, rank, group_size,
@@ -220,10 +213,10 @@ def _render_passes(backend, image, params, grid, mine, copier, chunk, n_passes, 
                 begin = k * chunk
             else:
                 begin = 0
-            first, n = sample_share(begin, chunk, group_size, member)
             if exact_in_group is not None:
-                sums = _exact_tile_sums(backend, tp, first, n, group_size, member, *exact_in_group)
+                sums = _exact_tile_sums(backend, tp, begin, chunk, group_size, member, *exact_in_group)
             else:
+                first, n = sample_share(begin, chunk, group_size, member)
                 sums = backend.render_sums(tp, first, n) if n > 0 else backend.zeros(tp)
                 reduce_in_group(sums)
             if member == (group_size - 1 if exact_in_group is not None else 0):
@@ -284,6 +277,9 @@ class GpuTileBackend:
 
     def sums(self, params):
         return self._tensor(params)
+
+    def reserve(self, params, sample_count):
+        return self.renderer.reserve_samples(params, sample_count)
 
     def trace(self, params, sample_begin, sample_count):
         return self.renderer.trace_samples(params, sample_begin, sample_count)

@@ -84,7 +84,15 @@ def _exact_worker(rank, world, port, asset_root, out_path):
     with Renderer(0) as r:
         r.upload(scene)
         backend = GpuSumsBackend(r, scene.params, torch.device("cuda", 0))
-        sums = render_pass_exact(backend, 0, 7, world, rank, send, recv)
+        # rank 1 holds a single sample in flight: the pass then takes rounds of one sample per rank
+        r.set_option(F.RT_OPT_SAMPLES_IN_FLIGHT, 1 if rank == 1 else 0)
+
+        def agree_min(n):
+            t = torch.tensor([n])
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return int(t)
+
+        sums = render_pass_exact(backend, 0, 7, world, rank, send, recv, agree_min=agree_min)
         if rank == 0:
             np.save(out_path, sums.cpu().numpy())
     dist.barrier()

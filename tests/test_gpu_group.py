@@ -47,6 +47,27 @@ def test_group_equals_one_context_with_pieces_and_incremental(renderer, asset_ro
         assert np.array_equal(bits(g.render_sums(s.params, 5, 1)), bits(renderer.render_sums(s.params, 5, 1)))
 
 
+def test_group_takes_a_large_pass_in_rounds(renderer, asset_root):
+    # 16 samples, three members holding two samples in flight each: rounds of 2+2+2, 2+2+2, 2+2+0
+    s = scenes.room(asset_root, w=40, h=24, spp=16, bounces=8)
+    renderer.upload(s)
+    one = renderer.render_sums(s.params, 3, 16)
+    with RendererGroup([0, 0, 0]) as g:
+        g.upload(s)
+        g.set_option(F.RT_OPT_SAMPLES_IN_FLIGHT, 2)
+        assert np.array_equal(bits(g.render_sums(s.params, 3, 16)), bits(one))
+        assert g.stats()["paths"] == 40 * 24 * 16
+        g.set_option(F.RT_OPT_SAMPLES_IN_FLIGHT, 0)
+        assert np.array_equal(bits(g.render_sums(s.params, 3, 16)), bits(one))
+    # the reserved room is what one trace call takes
+    renderer.set_option(F.RT_OPT_SAMPLES_IN_FLIGHT, 2)
+    assert renderer.reserve_samples(s.params, 9) == 2 and renderer.trace_samples(s.params, 0, 9) == 2
+    renderer.set_option(F.RT_OPT_SAMPLES_IN_FLIGHT, 0)
+    assert renderer.reserve_samples(s.params, 9) == 9 and renderer.trace_samples(s.params, 0, 9) == 9
+    with pytest.raises(RtError):
+        renderer.reserve_samples(s.params, 0)
+
+
 def test_group_errors():
     with pytest.raises(RtError):
         RendererGroup([])

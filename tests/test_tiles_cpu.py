@@ -90,9 +90,12 @@ class OracleTileBackend:
             self._sums = torch.zeros(h * w * 3, dtype=torch.float32)
         return self._sums
 
+    def reserve(self, params, count):
+        return min(count, 1)
+
     def trace(self, params, begin, count):
         from oracle import binding as O
-        n = min(count, 1)  # one sample in flight: every share goes through the piece-by-piece path
+        n = min(count, 1)  # one sample in flight: a pass of several samples per member takes several rounds
         self._pending = [torch.from_numpy(O.render_sums(self.scene, params, begin + j, 1).reshape(-1).copy()) for j in range(n)]
         return n
 
