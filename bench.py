@@ -42,17 +42,46 @@ VALU_PEAK_GINSTR = 1024 * 2.4 / 2.0  # 1024 SIMDs x 2.4 GHz, one wave64 vector i
 PROFILE = os.path.join(ROOT, "profiles", "r02_counters.json")
 
 
+def _code_only(text: str) -> str:
+    """C++ / make source without comments and without blank space (string literals kept)."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c == '"' or c == "'":  # a literal: copy through its closing quote
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            i = text.find("\n", i) if text.find("\n", i) >= 0 else n
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+        elif c.isspace():
+            i += 1
+        else:
+            out.append(c)
+            i += 1
+    return "".join(out)
+
+
 def kernel_source_hash() -> str:
     """Identifies the device code a counter profile belongs to: a hash over the
     sources of the render loop's kernels and of their launches, and the build flags
-    (the Makefile)."""
+    (the Makefile) — the code only: comments and blank space do not count."""
     import hashlib
 
     h = hashlib.sha256()
     base = os.path.join(ROOT, "raytracer_amd", "csrc")
     for path in [os.path.join(base, "device", n) for n in ("kernels.h", "layout.h", "rt_context.hip")] + [os.path.join(base, "Makefile")]:
-        with open(path, "rb") as f:
-            h.update(os.path.basename(path).encode() + b"\0" + f.read())
+        with open(path, encoding="utf-8") as f:
+            text = f.read()
+        if path.endswith("Makefile"):
+            text = "\n".join(line.split("#", 1)[0].rstrip() for line in text.splitlines())
+        else:
+            text = _code_only(text)
+        h.update(os.path.basename(path).encode() + b"\0" + text.encode())
     return h.hexdigest()[:16]
 
 

@@ -1103,11 +1103,12 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
 
 // ------------------------------------------------------- the whole bounce loop
 //
-// One launch for all bounces of a batch of paths: every wave owns a contiguous
-// block of the batch's paths and takes it through the bounce loop of
-// lib.rs:313-373 by itself — trace_loop over its block's rays, then shade_entry
-// over the same entries 64 at a time with the survivors written, packed, to the
-// same block of the other queue, and so on until no path of the block is alive.
+// One launch for all bounces of a batch of paths: every wave owns a share of the
+// batch's paths (blocks of 64 dealt to the waves in turn, stored in a stretch of
+// the queues that is the wave's own) and takes it through the bounce loop of
+// lib.rs:313-373 by itself — trace_loop over its rays, then shade_entry over the
+// same entries 64 at a time with the survivors written, packed, to the same
+// stretch of the other queue, and so on until none of its paths is alive.
 // Waves never wait for each other: there is no launch per bounce, no queue
 // counter, no compaction atomic, and on every SIMD some waves traverse (bound by
 // instruction issue) while others shade (bound by memory), with all of the
@@ -1117,6 +1118,7 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
 // For scenes whose only traversed family is the triangles (spheres and planes
 // absent or scanned where rays are created).  Dynamic LDS: the traversal
 // kernel's layout, then 256 floats (byte / 255).
+
 // What the shading half of k_path needs, kept in device memory rather than in the kernel's
 // argument block: arguments are fetched into scalar registers at the kernel's entry and would
 // stay there across the traversal loop, which has none to spare.

@@ -99,3 +99,16 @@ def test_every_declared_entry_point_is_bound_in_python_and_in_the_rust_binding()
     rust = open(os.path.join(ROOT, "bindings", "rt_mi355.rs")).read()
     bound = set(re.findall(r"pub fn (rt_\w+)\(", rust))
     assert declared <= bound, sorted(declared - bound)
+
+
+def test_counter_record_is_quoted_only_for_the_kernels_it_was_taken_from(monkeypatch):
+    """The hardware-counter record bench.py quotes is stamped with a hash of the kernels'
+    code (comments and blank space aside); a record of other kernels is not quoted."""
+    import argparse
+
+    import bench
+
+    assert bench._code_only('a = "x // y"; // c\n/* z */ b = \'"\';  int\tq;') == 'a="x // y";b=\'"\';intq;'
+    args = argparse.Namespace(workload="room", width=1920, height=1080, bounces=60, detail=4, fast=False)
+    monkeypatch.setattr(bench, "kernel_source_hash", lambda: "not the recorded one")
+    assert bench.recorded_counters(args) is None
