@@ -1191,9 +1191,9 @@ int rt_upload_scene(RtContext* ctx, const RtSceneDesc* s) {
         const RtMaterial& m = s->materials[i];
         if (m.kind > RT_MAT_LIGHT || m.color_kind > RT_COLOR_TEXTURE) return fail(ctx, RT_ERR_INVALID, "bad material kind");
         if (m.color_kind == RT_COLOR_TEXTURE) {
-            const uint64_t bytes = static_cast<uint64_t>(m.tex_width) * m.tex_height * 3;
+            const uint64_t texels = static_cast<uint64_t>(m.tex_width) * m.tex_height;  // (no overflow: two 32-bit factors)
             if (m.tex_width == 0 || m.tex_height == 0 || m.tex_offset > s->n_texel_bytes ||
-                bytes > s->n_texel_bytes - m.tex_offset)
+                texels > (s->n_texel_bytes - m.tex_offset) / 3)
                 return fail(ctx, RT_ERR_INVALID, "texture outside the texel array");
         }
     }

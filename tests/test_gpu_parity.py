@@ -418,6 +418,14 @@ def test_malformed_descriptions_are_refused(renderer):
     t.spheres["material"] = len(t.materials) - 1
     with pytest.raises(RtError, match="triangles only"):
         renderer.upload(t)
+    # a texture whose size in bytes does not fit 64 bits must not pass the size check by wrapping round
+    u = scenes.sphere_plane(w=16, h=8, spp=1)
+    m = np.zeros(1, dtype=MATERIAL_DT)
+    m["color_kind"], m["tex_width"], m["tex_height"] = F.RT_COLOR_TEXTURE, 0xFFFFFFFF, 0xFFFFFFFF
+    u.materials = np.concatenate([u.materials, m])
+    u.texels = np.zeros(12, np.uint8)
+    with pytest.raises(RtError, match="outside the texel array"):
+        renderer.upload(u)
     check_scene(renderer, s)  # the context stays usable
 
 
