@@ -891,10 +891,10 @@ __device__ __forceinline__ F3 color_sample(const DScene& sc, const DMaterial& m,
         de[k] = e - e0f;
     }
     const uint32_t* tex = in_global(sc.texels) + m.tex_first;
-    const size_t w = m.tex_width;
+    const size_t tiles_per_row = (static_cast<size_t>(m.tex_width) + (kTexTileW - 1u)) / kTexTileW;
     // byte -> byte/255 (vec3.rs:515-520) through a 256-entry table of exact quotients
     auto texel = [&](uint32_t x, uint32_t y) {
-        const uint32_t t = tex[x + y * w];
+        const uint32_t t = tex[((y / kTexTileH) * tiles_per_row + x / kTexTileW) * kTexTileTexels + (y % kTexTileH) * kTexTileW + x % kTexTileW];
         return f3(unit_of_byte[t & 255u], unit_of_byte[(t >> 8) & 255u], unit_of_byte[(t >> 16) & 255u]);
     };
     const F3 c00 = texel(i0[0], i0[1]), c01 = texel(i0[0], i1[1]);
@@ -1287,12 +1287,23 @@ __global__ void k_quantize(const float* sums, uint8_t* rgb8, uint32_t n_values, 
     rgb8[i] = to_u8(v * 255.0f);
 }
 
-// Upload-time repacking of one texture: packed RGB8 -> one 32-bit word per texel.
-__global__ void k_expand_texels(const uint8_t* rgb8, uint32_t* out, unsigned long long n_texels) {
+// Upload-time repacking of one texture: packed RGB8, row by row -> one 32-bit word per texel
+// in tiles of kTexTileW x kTexTileH texels (see layout.h); one thread per word of the tiled image.
+__global__ void k_expand_texels(const uint8_t* rgb8, uint32_t* out, uint32_t width, uint32_t height) {
+    const unsigned long long tiles_per_row = (static_cast<unsigned long long>(width) + (kTexTileW - 1u)) / kTexTileW;
+    const unsigned long long tile_rows = (static_cast<unsigned long long>(height) + (kTexTileH - 1u)) / kTexTileH;
     const unsigned long long i = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= n_texels) return;
-    const uint8_t* t = rgb8 + 3 * i;
-    out[i] = static_cast<uint32_t>(t[0]) | (static_cast<uint32_t>(t[1]) << 8) | (static_cast<uint32_t>(t[2]) << 16);
+    if (i >= tiles_per_row * tile_rows * kTexTileTexels) return;
+    const unsigned long long tile = i / kTexTileTexels;
+    const uint32_t in_tile = static_cast<uint32_t>(i % kTexTileTexels);
+    const unsigned long long x = (tile % tiles_per_row) * kTexTileW + in_tile % kTexTileW;
+    const unsigned long long y = (tile / tiles_per_row) * kTexTileH + in_tile / kTexTileW;
+    uint32_t word = 0;  // padding of the edge tiles: never sampled
+    if (x < width && y < height) {
+        const uint8_t* t = rgb8 + 3 * (y * width + x);
+        word = static_cast<uint32_t>(t[0]) | (static_cast<uint32_t>(t[1]) << 8) | (static_cast<uint32_t>(t[2]) << 16);
+    }
+    out[i] = word;
 }
 
 // Self-test of the shared-reciprocal division: compares div_by2 with `/` bit for

@@ -1152,6 +1152,12 @@ int rt_set_option(RtContext* ctx, uint32_t option, uint64_t value) {
     }
 }
 
+// Words a texture takes on the device: whole tiles (see layout.h).
+static uint64_t tiled_texels(uint32_t width, uint32_t height) {
+    return ((static_cast<uint64_t>(width) + kTexTileW - 1) / kTexTileW) * ((static_cast<uint64_t>(height) + kTexTileH - 1) / kTexTileH) *
+           kTexTileTexels;
+}
+
 int rt_upload_scene(RtContext* ctx, const RtSceneDesc* s) {
     if (!ctx || !s) return RT_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1277,7 +1283,7 @@ int rt_upload_scene(RtContext* ctx, const RtSceneDesc* s) {
             mats[i] = DMaterial{m.kind, m.param, m.color_kind, {m.rgb[0], m.rgb[1], m.rgb[2]}, m.tex_width, m.tex_height, 0};
             if (m.color_kind == RT_COLOR_TEXTURE) {
                 mats[i].tex_first = n_texels;
-                n_texels += static_cast<uint64_t>(m.tex_width) * m.tex_height;
+                n_texels += tiled_texels(m.tex_width, m.tex_height);
             }
         }
         {
@@ -1290,9 +1296,10 @@ int rt_upload_scene(RtContext* ctx, const RtSceneDesc* s) {
             for (uint32_t i = 0; !rc && i < s->n_materials; ++i) {
                 const RtMaterial& m = s->materials[i];
                 if (m.color_kind != RT_COLOR_TEXTURE) continue;
-                const unsigned long long nt = static_cast<unsigned long long>(m.tex_width) * m.tex_height;
+                const uint64_t nt = tiled_texels(m.tex_width, m.tex_height);
+                if ((nt + 255) / 256 > 0x7FFFFFFFull) { rc = fail(ctx, RT_ERR_INVALID, "texture too large"); break; }
                 hipLaunchKernelGGL(k_expand_texels, dim3(static_cast<uint32_t>((nt + 255) / 256)), dim3(256), 0, nullptr,
-                                   d_rgb8 + m.tex_offset, ctx->texels + mats[i].tex_first, nt);
+                                   d_rgb8 + m.tex_offset, ctx->texels + mats[i].tex_first, m.tex_width, m.tex_height);
                 if (hipGetLastError() != hipSuccess) rc = fail(ctx, RT_ERR_HIP, "texture expansion launch failed");
             }
             if (hipDeviceSynchronize() != hipSuccess && !rc) rc = fail(ctx, RT_ERR_HIP, "texture expansion failed");
