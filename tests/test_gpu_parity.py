@@ -11,6 +11,7 @@ import pytest
 
 from oracle import binding as O
 from raytracer_amd import _ffi as F
+from raytracer_amd import parse
 from raytracer_amd.renderer import RtError
 
 from . import scenes
@@ -76,6 +77,33 @@ def test_mesh_with_vertex_normals(renderer, asset_root):
 
 def test_textured_room(renderer, asset_root):
     check_scene(renderer, scenes.room(asset_root, w=64, h=36, spp=3, bounces=20))
+
+
+def test_textures_of_sizes_that_do_not_fill_the_device_tiles(renderer, tmp_path):
+    # The device keeps texels in tiles of 8 x 4: widths and heights below, at and just past a
+    # tile's, a single texel, and texture coordinates far outside [0, 1] (wrapped by
+    # material.rs:197-206) so that every edge texel, first and last row included, is sampled.
+    from raytracer_amd import assets
+
+    rng = np.random.default_rng(12)
+    sizes = [(1, 1), (2, 2), (7, 3), (8, 4), (9, 5), (13, 7), (16, 9), (31, 33)]
+    d = tmp_path / "obj" / "quads"
+    d.mkdir(parents=True)
+    w = assets.ObjWriter()
+    for k, (tw, th) in enumerate(sizes):
+        assets.write_ppm(str(d / f"t{k}.ppm"), rng.integers(0, 256, size=(th, tw, 3), dtype=np.uint8))
+        w.add_material(f"m{k}", map_kd=f"t{k}.ppm")
+        x0, y0 = -2.0 + (k % 4), 0.1 + (k // 4) * 1.1
+        verts = [(x0, y0, 0), (x0 + 0.95, y0, 0.2), (x0 + 0.95, y0 + 1.0, 0.2), (x0, y0 + 1.0, 0)]
+        uvs = [(-1.3, -0.7), (2.6, -0.7), (2.6, 1.9), (-1.3, 1.9)]
+        w.add(f"m{k}", verts, [(0, 1, 2), (0, 2, 3)], uvs=uvs)
+    w.write(str(d / "quads.obj"), "quads.mtl")
+    text = ("screen(-2.1 2.4 2, 4.2 0 0, 0 -2.4 0, 96, 56, 3, 5)\ncamera(0 1.2 6)\nspheres()\nplanes()\n"
+            "obj((quads/quads))\ntriangles()\n")
+    s = parse(text, str(tmp_path))
+    assert len(s.triangles) == 16 and int((s.materials["color_kind"] == F.RT_COLOR_TEXTURE).sum()) == len(sizes)
+    gpu = check_scene(renderer, s)
+    assert len(np.unique(bits(gpu))) > 500  # the textures are seen, not one flat colour
 
 
 def test_tree_of_overlapping_leaf_quads(renderer, asset_root):
