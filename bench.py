@@ -225,7 +225,9 @@ def main() -> None:
     ap.add_argument("--spp", type=int, default=None)
     ap.add_argument("--bounces", type=int, default=None)
     ap.add_argument("--detail", type=int, default=4, help="size of the generated scene (4 = 2.9e5 / 8.2e4 / 1.0e6 triangles)")
-    ap.add_argument("--tile", type=int, default=4096, help="tile edge of the room16k workload")
+    ap.add_argument("--tile", type=int, default=None,
+                    help="tile edge of the room16k workload (default: 8192 on one or two GPUs, where the larger batch "
+                         "renders 12 %% faster, 4096 beyond, so that every GPU has several tiles)")
     ap.add_argument("--trace-waves-per-cu", type=int, default=0, help="cap on resident traversal waves per CU (0 = automatic)")
     ap.add_argument("--shade-groups", type=int, default=None, help="shading workgroups per CU (library default: 8)")
     ap.add_argument("--chains", type=int, default=None, help="independent chains a batch is split into (library default: 2)")
@@ -252,6 +254,8 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.tile is None:
+        args.tile = 8192 if world <= 2 else 4096
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
