@@ -15,6 +15,16 @@ in the reference checkout, so the scene is the generated stand-in of
 raytracer_amd.assets.write_room (same camera as scenes/breakfast-room).
 
 Rank 0 prints one JSON line.
+
+Several GPUs.  Under torch.distributed.run (RANK / WORLD_SIZE set) every process is
+one rank on its own GPU.  Started plainly with --gpus N > 1, this program starts
+its N ranks itself, as the reference starts its own workers inside the one call
+(/root/reference/src/lib.rs:195-219): before anything has touched a GPU it runs
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child
+process, passes rank 0's JSON line through and exits with the child's status.
+--backend group renders the same step inside ONE process instead, through the
+library's own GPU list (rt_group_*: one context and one host thread per GPU, the
+sums handed from GPU to GPU in sample order, no collective library involved).
 """
 from __future__ import annotations
 
@@ -213,6 +223,101 @@ def cpu_baseline(scene: Scene, args) -> dict:
             "rays_per_sample": round(c.segments / max(c.paths, 1), 3)}
 
 
+def launch_ranks(n: int, argv: list[str]) -> int:
+    """Start this program's N ranks as a child process group (torch.distributed.run on
+    127.0.0.1, a free port) and return its exit status.  Nothing in this process has
+    touched a GPU or initialised HIP: the parent only waits.  Rank 0's JSON line reaches
+    stdout through the inherited descriptor."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print(f"[bench] starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=dict(os.environ)).returncode
+
+
+def main_group(args) -> None:
+    """--backend group: the step rendered by ONE process through the library's GPU list
+    (RendererGroup = rt_group_*): every GPU traces its contiguous piece of the pass's samples
+    on a host thread of its own, the running sums go from GPU to GPU in sample order, the
+    last holder resolves.  The stored bytes are the single-GPU bytes."""
+    import torch  # (before the library: one HIP runtime per process)
+
+    from raytracer_amd.renderer import Renderer, RendererGroup
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render loop has no CPU path")
+    if args.workload == "room16k":
+        raise SystemExit("--backend group renders whole frames; the tiled 16K workload runs with --backend ranks")
+    n = args.gpus
+    ordinals = [0] * n if args.rehearse_on_one_gpu else list(range(n))
+    if not args.rehearse_on_one_gpu and torch.cuda.device_count() < n:
+        raise SystemExit(f"--gpus {n} but only {torch.cuda.device_count()} visible")
+    with Renderer(0) as builder:
+        scene = load_scene(args, builder)
+    g = RendererGroup(ordinals)
+    g.upload(scene)
+    chains = 2 if args.chains is None else args.chains
+    g.set_option(F.RT_OPT_CHAINS, chains)
+    g.set_option(F.RT_OPT_TRACE_WAVES_PER_CU, args.trace_waves_per_cu)
+    if args.shade_groups is not None:
+        g.set_option(F.RT_OPT_SHADE_GROUPS_PER_CU, args.shade_groups)
+    for kv in args.opt:
+        name, value = kv.split("=")
+        g.set_option(getattr(F, "RT_OPT_" + name), int(value))
+    if args.fast:
+        g.set_option(F.RT_OPT_FAST_SLAB, 1)
+    params = scene.params
+    rgb8 = np.zeros((args.height, args.width, 3), dtype=np.uint8)
+
+    def sync_all():
+        for d in set(ordinals):
+            torch.cuda.synchronize(d)
+
+    for _ in range(args.warmup):
+        g.render(params, rgb8)
+    g.set_option(F.RT_OPT_TIME_KERNELS, 1)
+    g.reset_stats()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g.render(params, rgb8)
+    sync_all()
+    dt = time.perf_counter() - t0
+    st = g.stats()
+    before = rgb8.copy()
+    g.render(params, rgb8)
+    rays_per_s = st["segments"] / dt
+    out = {
+        "metric": "Mrays/s (all bounces) breakfast-room 1080p" if args.workload == "room" else f"Mrays/s (all bounces) {args.workload}",
+        "value": round(rays_per_s / 1e6, 3), "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": scene_text(args)[1].format(n=len(scene.triangles), w=args.width, h=args.height, spp=args.spp, b=args.bounces, t=0),
+            "partition": "samples",
+            "collective": "none: one process, one host thread per GPU, per-pixel sums copied GPU to GPU in sample order (rt_group_*)",
+            "backend": "group",
+            "arithmetic": "fast slab test (not bit-exact)" if args.fast else "exact (bit-identical to the CPU oracle and to one GPU)",
+        },
+        "bench_args": {"workload": args.workload, "width": args.width, "height": args.height, "spp": args.spp,
+                       "bounces": args.bounces, "detail": args.detail, "chains": chains, "gpu_ordinals": ordinals},
+        "samples_per_s": round(st["paths"] / dt, 1),
+        "image_repeats": bool(np.array_equal(before, rgb8)),
+        "rays_per_sample": round(st["segments"] / max(st["paths"], 1), 3),
+        "roofline": {"bound": "valu_issue", "kernel": "k_trace<TRIANGLE>", "unit": "G wave-instr/s", "peak": VALU_PEAK_GINSTR,
+                     "achieved": None, "frac": None, "traffic": None,
+                     "avg_launch_ms": round(st["trace_ms"] / max(st["trace_launches"], 1), 4), "launches": int(st["trace_launches"]),
+                     "note": "fractions are quoted by the one-GPU run; this line times the GPU list"},
+    }
+    print(json.dumps(out), flush=True)
+    g.close()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -240,6 +345,12 @@ def main() -> None:
     ap.add_argument("--exact", action="store_true",
                     help="with several GPUs: hand the running sums from rank to rank in sample order instead of one "
                          "reduce, so that the image is the single-GPU image bit for bit")
+    ap.add_argument("--backend", choices=("ranks", "group"), default="ranks",
+                    help="with several GPUs: one process per GPU over torch.distributed/RCCL (ranks, the default), or one "
+                         "process driving all GPUs through the library's rt_group_* entry points (group)")
+    ap.add_argument("--dry-run-launch", action="store_true",
+                    help="development aid for machines without a GPU: start the ranks, form the process group over gloo, "
+                         "agree on a value and print a line without any rendering (no number is measured)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development aid: run all ranks on GPU 0 and reduce over gloo through host memory, to exercise "
                          "the multi-rank control flow on a one-GPU machine (numbers are meaningless)")
@@ -247,6 +358,13 @@ def main() -> None:
     dw, dh, dspp, db = WORKLOADS[args.workload]
     args.width, args.height = args.width or dw, args.height or dh
     args.spp, args.bounces = args.spp or dspp, args.bounces if args.bounces is not None else db
+
+    if args.backend == "group" and args.gpus > 1:
+        if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
+            raise SystemExit("--backend group is one process for all GPUs: start it plainly, not under torch.distributed.run")
+        return main_group(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -257,7 +375,23 @@ def main() -> None:
     if args.tile is None:
         args.tile = 8192 if world <= 2 else 4096
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start bench.py plainly (it starts its own ranks) or "
+                         f"under torch.distributed.run with --nproc-per-node {args.gpus}")
+    if args.dry_run_launch:
+        # the launch path alone: rendezvous, one collective, rank 0's line
+        if world > 1:
+            dist.init_process_group("gloo")
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"dry_run_launch": True, "n_gpus": world, "ranks_seen": int(t.item()) == world * (world + 1) // 2,
+                              "value": None, "config": {"partition": "samples", "backend": "ranks",
+                                                        "collective": "reduce(sum) of f32 radiance per step"}}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render loop has no CPU path")
     if args.rehearse_on_one_gpu:
@@ -529,6 +663,7 @@ def main() -> None:
                 "workload": scene_text(args)[1].format(n=len(scene.triangles), w=args.width, h=args.height, spp=args.spp,
                                                        b=args.bounces, t=args.tile),
                 "partition": ("tiles" if tiled else "samples") if world > 1 else "none",
+                "backend": "ranks" if world > 1 else "one process",
                 "collective": ("none (each rank writes its tiles into the mapped file)" if tiled
                                else "chain of send/recv of f32 radiance per step (exact fold)" if args.exact
                                else "reduce(sum) of f32 radiance per step") if world > 1 else "none",

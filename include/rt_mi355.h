@@ -242,8 +242,10 @@ typedef enum RtOption {
      * where it is the faster loop (several times faster for previews and single-sample passes).
      * Results do not depend on it. */
     RT_OPT_FUSED_LOOP = 17,
+    RT_OPT_DEBUG_THROW = 19, /* test hook: 1 makes this very rt_set_option call fail inside with std::bad_alloc, 2 with another
+                              * exception; the call must come back with RT_ERR_OOM / RT_ERR_HIP (nothing throws across the boundary) */
     RT_OPT_PATH_GROUP = 18, /* tuning of that launch: paths a wave takes through all bounces at a time (multiple of 64; default 16384) */
-    RT_OPT_TRACE_WAVES_PER_CU = 12 /* traversal waves resident per compute unit (0 = as many as fit, else 1..32): leaves room for kernels of another context on the same GPU */
+    RT_OPT_TRACE_WAVES_PER_CU = 12 /* traversal waves resident per compute unit (0 = as many as fit, else 1..32), for the per-bounce traversal launches and the one-launch bounce loop alike: leaves room for kernels of another context on the same GPU */
 } RtOption;
 
 typedef struct RtContext RtContext;
@@ -346,18 +348,23 @@ int rt_trace_primary(RtContext* ctx, const RtRenderParams* params,
 int rt_trace_rays(RtContext* ctx, const float* origins, const float* directions,
                   uint64_t n_rays, RtHitRecord* out);
 
-/* rt_trace_rays for callers that cannot allocate device memory (code under HIP
- * graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has
- * no counterpart in the reference.  Same results as rt_trace_rays, bit for bit,
- * but every intermediate (ray queue, hit records, traversal stack overflow)
- * lives in a fixed 64 MiB array that is part of the library's code object — one
- * copy per GPU, held until the process ends — so the call performs no
- * hipMalloc / hipFree and no host allocation.  At most 524288 rays per call
- * (RT_ERR_INVALID beyond that).  `origins`, `directions` and `out` are host
- * pointers, or device pointers on this context's GPU when `on_device` is
- * non-zero.  All contexts on one GPU share that GPU's array: calls that overlap
- * in time on one GPU (from different contexts or threads) race; calls in
- * sequence are independent of each other. */
+/* rt_trace_rays for callers that cannot allocate device memory (tight serving
+ * loops, harnesses that forbid hipMalloc).  It has no counterpart in the
+ * reference.  Same results as rt_trace_rays, bit for bit, but every intermediate
+ * (ray queue, hit records, traversal stack overflow) lives in a fixed 64 MiB
+ * array that is part of the library's code object — one copy per GPU, held until
+ * the process ends — so the call performs no hipMalloc / hipFree and no host
+ * allocation.  At most 524288 rays per call (RT_ERR_INVALID beyond that).
+ * `origins`, `directions` and `out` are host pointers, or device pointers on this
+ * context's GPU when `on_device` is non-zero.  The call works on the context's
+ * own non-blocking stream, waits for it and copies results before it returns:
+ * it is a blocking call (not one to make while a stream capture is active on the
+ * calling thread), and device inputs must be complete — and `out` no longer in
+ * use — by the caller's own synchronisation before the call, since the library's
+ * stream is not ordered against any stream of the caller.  All contexts on one
+ * GPU share that GPU's array: calls that overlap in time on one GPU (from
+ * different contexts or threads) race; calls in sequence are independent of
+ * each other. */
 int rt_trace_rays_noalloc(RtContext* ctx, const float* origins, const float* directions,
                           uint64_t n_rays, RtHitRecord* out, int on_device);
 

@@ -36,6 +36,7 @@
 #include <string>
 #include <vector>
 
+#include "abi_guard.h"
 #include "rt_mi355.h"
 
 namespace rtb {
@@ -606,12 +607,12 @@ int build_bvh_on_gpu(RtContext* ctx, Shape* shapes, uint32_t n, RtNode** nodes_o
 
 }  // namespace
 
-extern "C" int rt_build_bvh_triangles(RtContext* ctx, RtTriangle* shapes, uint32_t n, RtNode** nodes, uint32_t* n_nodes) {
+extern "C" int rt_build_bvh_triangles(RtContext* ctx, RtTriangle* shapes, uint32_t n, RtNode** nodes, uint32_t* n_nodes) try {
     return build_bvh_on_gpu(ctx, shapes, n, nodes, n_nodes);
-}
+} RT_ABI_END_CTX(ctx)
 
-extern "C" int rt_build_bvh_spheres(RtContext* ctx, RtSphere* shapes, uint32_t n, RtNode** nodes, uint32_t* n_nodes) {
+extern "C" int rt_build_bvh_spheres(RtContext* ctx, RtSphere* shapes, uint32_t n, RtNode** nodes, uint32_t* n_nodes) try {
     return build_bvh_on_gpu(ctx, shapes, n, nodes, n_nodes);
-}
+} RT_ABI_END_CTX(ctx)
 
-extern "C" void rt_free(void* p) { std::free(p); }
+extern "C" void rt_free(void* p) try { std::free(p); } RT_ABI_END_VOID

@@ -10,9 +10,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
+#include "abi_guard.h"
 #include "kernels.h"
 #include "layout.h"
 #include "rt_mi355.h"
@@ -631,7 +633,10 @@ int launch_path_variant(RtContext* ctx, PathArgs a, const FrameArgs& f, uint32_t
         slot = RtContext::Occupancy{fn, lds, per_cu};
         it = &slot;
     }
-    uint32_t grid = static_cast<uint32_t>(ctx->n_cus) * static_cast<uint32_t>(it->per_cu);
+    // the caller's cap on resident traversal waves (RT_OPT_TRACE_WAVES_PER_CU) holds for this loop too
+    const uint32_t wave_cap = ctx->tune_waves_per_cu ? ctx->tune_waves_per_cu : 32u;
+    const uint32_t groups_per_cu = std::max<uint32_t>(1u, std::min<uint32_t>(static_cast<uint32_t>(it->per_cu), wave_cap / WAVES));
+    uint32_t grid = static_cast<uint32_t>(ctx->n_cus) * groups_per_cu;
     // a small batch: no more waves than blocks of 64 paths
     const uint32_t blocks_of_64 = (a.n_paths + 63u) / 64u;
     grid = std::max(1u, std::min(grid, (blocks_of_64 + WAVES - 1) / WAVES));
@@ -978,6 +983,14 @@ bool create_chains(RtContext* ctx) {
 // For the other translation units of this library (bvh_build.hip): record an
 // error on the context; make the context's GPU current and hand out its stream.
 int rt_context_fail(RtContext* ctx, int code, const std::string& msg) { return fail(ctx, code, msg); }
+int rt_abi_caught(RtContext* ctx, bool out_of_memory) noexcept {
+    // the message buffer was reserved at creation: a literal of this length is stored without allocating
+    try {
+        if (ctx) ctx->error.assign(out_of_memory ? "out of host memory" : "internal error (an exception was caught at the C boundary)");
+    } catch (...) {
+    }
+    return out_of_memory ? RT_ERR_OOM : RT_ERR_HIP;
+}
 int rt_context_device(RtContext* ctx, hipStream_t* stream) {
     if (!ctx) return RT_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -987,7 +1000,7 @@ int rt_context_device(RtContext* ctx, hipStream_t* stream) {
 
 extern "C" {
 
-uint32_t rt_abi_version(void) { return RT_ABI_VERSION; }
+uint32_t rt_abi_version(void) try { return RT_ABI_VERSION; } RT_ABI_END_VALUE(0u)
 
 // Message of the last failed rt_create of this thread (there is no context to hold it).
 static thread_local char g_create_error[512] = "";
@@ -1017,7 +1030,7 @@ static int count_hip_runtimes(char* paths, size_t cap) {
     return found.n;
 }
 
-int rt_create(int device_ordinal, RtContext** out) {
+int rt_create(int device_ordinal, RtContext** out) try {
     if (!out) return RT_ERR_INVALID;
     *out = nullptr;
     g_create_error[0] = 0;
@@ -1058,6 +1071,7 @@ int rt_create(int device_ordinal, RtContext** out) {
     }
     ctx->scratch = static_cast<unsigned char*>(scratch_ptr);
     ctx->error.reserve(256);  // later messages of that length are stored without allocating
+    ctx->events.reserve(4096);  // timed launches take their event pairs from here without growing it
     ctx->d_inline_tests = ctx->d_stats + 7;
     ctx->launch_stream = ctx->stream;
     ctx->chain_stream[0] = ctx->stream;
@@ -1065,9 +1079,9 @@ int rt_create(int device_ordinal, RtContext** out) {
     ctx->max_grid_threads = static_cast<uint32_t>(ctx->n_cus) * 32u * kTraceBlock;  // 32 waves per CU at most
     *out = ctx;
     return RT_OK;
-}
+} RT_ABI_END_INT
 
-void rt_destroy(RtContext* ctx) {
+void rt_destroy(RtContext* ctx) try {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
@@ -1085,14 +1099,14 @@ void rt_destroy(RtContext* ctx) {
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
-}
+} RT_ABI_END_VOID
 
-const char* rt_last_error(const RtContext* ctx) {
+const char* rt_last_error(const RtContext* ctx) try {
     if (ctx) return ctx->error.c_str();
     return g_create_error[0] ? g_create_error : "null context";
-}
+} RT_ABI_END_VALUE("internal error")
 
-int rt_set_option(RtContext* ctx, uint32_t option, uint64_t value) {
+int rt_set_option(RtContext* ctx, uint32_t option, uint64_t value) try {
     if (!ctx) return RT_ERR_INVALID;
     switch (option) {
         case RT_OPT_COUNT_TRAVERSAL: ctx->opt_count = value != 0; return RT_OK;
@@ -1144,13 +1158,18 @@ int rt_set_option(RtContext* ctx, uint32_t option, uint64_t value) {
             if (value < 64 || value > (1u << 24) || value % 64) return fail(ctx, RT_ERR_INVALID, "path group must be a multiple of 64 in 64..2^24");
             ctx->tune_path_group = static_cast<uint32_t>(value);
             return RT_OK;
+        case RT_OPT_DEBUG_THROW:
+            // test hook of the boundary's exception guard: the exception leaves through this very function
+            if (value == 1) throw std::bad_alloc();
+            if (value == 2) throw std::runtime_error("RT_OPT_DEBUG_THROW");
+            return RT_OK;
         case RT_OPT_FUSED_LOOP:
             if (value > 2) return fail(ctx, RT_ERR_INVALID, "fused bounce loop: 0 (never), 1 (whenever possible) or 2 (for small batches)");
             ctx->opt_fused = static_cast<uint32_t>(value);
             return RT_OK;
         default: return fail(ctx, RT_ERR_INVALID, "unknown option");
     }
-}
+} RT_ABI_END_CTX(ctx)
 
 // Words a texture takes on the device: whole tiles (see layout.h).
 static uint64_t tiled_texels(uint32_t width, uint32_t height) {
@@ -1158,7 +1177,7 @@ static uint64_t tiled_texels(uint32_t width, uint32_t height) {
            kTexTileTexels;
 }
 
-int rt_upload_scene(RtContext* ctx, const RtSceneDesc* s) {
+int rt_upload_scene(RtContext* ctx, const RtSceneDesc* s) try {
     if (!ctx || !s) return RT_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1349,10 +1368,10 @@ int rt_upload_scene(RtContext* ctx, const RtSceneDesc* s) {
     }
     ctx->has_scene = true;
     return RT_OK;
-}
+} RT_ABI_END_CTX(ctx)
 
 int rt_render_sums(RtContext* ctx, const RtRenderParams* p, uint32_t sample_begin, uint32_t sample_count, float* sums,
-                   int sums_on_device) {
+                   int sums_on_device) try {
     int rc = require_scene(ctx);
     if (rc) return rc;
     Region r;
@@ -1367,10 +1386,10 @@ int rt_render_sums(RtContext* ctx, const RtRenderParams* p, uint32_t sample_begi
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stats.render_ms += timer.ms();
     return RT_OK;
-}
+} RT_ABI_END_CTX(ctx)
 
 int rt_render_sums_onto(RtContext* ctx, const RtRenderParams* p, uint32_t sample_begin, uint32_t sample_count, float* sums,
-                        int sums_on_device) {
+                        int sums_on_device) try {
     int rc = require_scene(ctx);
     if (rc) return rc;
     Region r;
@@ -1385,9 +1404,9 @@ int rt_render_sums_onto(RtContext* ctx, const RtRenderParams* p, uint32_t sample
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stats.render_ms += timer.ms();
     return RT_OK;
-}
+} RT_ABI_END_CTX(ctx)
 
-int rt_trace_samples(RtContext* ctx, const RtRenderParams* p, uint32_t sample_begin, uint32_t sample_count, uint32_t* traced) {
+int rt_trace_samples(RtContext* ctx, const RtRenderParams* p, uint32_t sample_begin, uint32_t sample_count, uint32_t* traced) try {
     int rc = require_scene(ctx);
     if (rc) return rc;
     Region r;
@@ -1408,9 +1427,9 @@ int rt_trace_samples(RtContext* ctx, const RtRenderParams* p, uint32_t sample_be
     *traced = nb;
     ctx->stats.render_ms += timer.ms();
     return RT_OK;
-}
+} RT_ABI_END_CTX(ctx)
 
-int rt_reserve_samples(RtContext* ctx, const RtRenderParams* p, uint32_t sample_count, uint32_t* in_flight) {
+int rt_reserve_samples(RtContext* ctx, const RtRenderParams* p, uint32_t sample_count, uint32_t* in_flight) try {
     int rc = require_scene(ctx);
     if (rc) return rc;
     Region r;
@@ -1422,9 +1441,9 @@ int rt_reserve_samples(RtContext* ctx, const RtRenderParams* p, uint32_t sample_
     if (rc) return rc;
     *in_flight = std::min<uint32_t>(static_cast<uint32_t>(S), sample_count);
     return RT_OK;
-}
+} RT_ABI_END_CTX(ctx)
 
-int rt_fold_samples(RtContext* ctx, const RtRenderParams* p, int carry_on, float* sums, int sums_on_device) {
+int rt_fold_samples(RtContext* ctx, const RtRenderParams* p, int carry_on, float* sums, int sums_on_device) try {
     if (!ctx) return RT_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     Region r;
@@ -1448,10 +1467,10 @@ int rt_fold_samples(RtContext* ctx, const RtRenderParams* p, int carry_on, float
     ctx->pending_samples = 0;
     ctx->stats.render_ms += timer.ms();
     return RT_OK;
-}
+} RT_ABI_END_CTX(ctx)
 
 int rt_resolve(RtContext* ctx, const RtRenderParams* p, const float* sums, int sums_on_device, uint32_t n_samples,
-               int running_average, uint32_t sample_iteration, uint8_t* rgb8) {
+               int running_average, uint32_t sample_iteration, uint8_t* rgb8) try {
     if (!ctx) return RT_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     Region r;
@@ -1469,9 +1488,9 @@ int rt_resolve(RtContext* ctx, const RtRenderParams* p, const float* sums, int s
     HIP_TRY(ctx, hipMemcpyAsync(rgb8, w.rgb8, r.n_pixels * 3, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
-}
+} RT_ABI_END_CTX(ctx)
 
-int rt_render(RtContext* ctx, const RtRenderParams* p, uint8_t* rgb8, RtProgressFn progress, void* user) {
+int rt_render(RtContext* ctx, const RtRenderParams* p, uint8_t* rgb8, RtProgressFn progress, void* user) try {
     int rc = require_scene(ctx);
     if (rc) return rc;
     Region r;
@@ -1504,9 +1523,9 @@ int rt_render(RtContext* ctx, const RtRenderParams* p, uint8_t* rgb8, RtProgress
     }
     ctx->stats.render_ms += timer.ms();
     return RT_OK;
-}
+} RT_ABI_END_CTX(ctx)
 
-int rt_trace_primary(RtContext* ctx, const RtRenderParams* p, uint32_t sample_index, int jitter, RtHitRecord* out) {
+int rt_trace_primary(RtContext* ctx, const RtRenderParams* p, uint32_t sample_index, int jitter, RtHitRecord* out) try {
     int rc = require_scene(ctx);
     if (rc) return rc;
     Region r;
@@ -1528,9 +1547,9 @@ int rt_trace_primary(RtContext* ctx, const RtRenderParams* p, uint32_t sample_in
     rc = harvest(ctx);
     if (rc) return rc;
     return download_hits(ctx, w.q[0], n, out);
-}
+} RT_ABI_END_CTX(ctx)
 
-int rt_trace_rays(RtContext* ctx, const float* origins, const float* directions, uint64_t n_rays, RtHitRecord* out) {
+int rt_trace_rays(RtContext* ctx, const float* origins, const float* directions, uint64_t n_rays, RtHitRecord* out) try {
     int rc = require_scene(ctx);
     if (rc) return rc;
     if (n_rays == 0) return RT_OK;
@@ -1555,7 +1574,7 @@ int rt_trace_rays(RtContext* ctx, const float* origins, const float* directions,
     rc = harvest(ctx);
     if (rc) return rc;
     return download_hits(ctx, w.q[0], n, out);
-}
+} RT_ABI_END_CTX(ctx)
 
 // Error paths of the entry point below: a literal copied into the context's message
 // buffer (capacity reserved at creation), no temporary strings.
@@ -1574,7 +1593,7 @@ static int fail_literal(RtContext* ctx, int code, const char* msg) {
     } while (0)
 
 int rt_trace_rays_noalloc(RtContext* ctx, const float* origins, const float* directions, uint64_t n_rays, RtHitRecord* out,
-                          int on_device) {
+                          int on_device) try {
     if (!ctx) return RT_ERR_INVALID;
     if (!ctx->has_scene) return fail_literal(ctx, RT_ERR_STATE, "no scene uploaded");
     if (n_rays == 0) return RT_OK;
@@ -1631,9 +1650,9 @@ int rt_trace_rays_noalloc(RtContext* ctx, const float* origins, const float* dir
                                         on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY_LITERAL(ctx, hipStreamSynchronize(ctx->stream));
     return harvest(ctx);
-}
+} RT_ABI_END_CTX(ctx)
 
-int rt_self_test(RtContext* ctx, uint32_t which, uint64_t n_cases, uint64_t* failures) {
+int rt_self_test(RtContext* ctx, uint32_t which, uint64_t n_cases, uint64_t* failures) try {
     if (!ctx || !failures) return RT_ERR_INVALID;
     if (which != RT_SELF_TEST_DIVISION && which != RT_SELF_TEST_RECIPROCAL) return fail(ctx, RT_ERR_INVALID, "unknown self test");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1652,15 +1671,15 @@ int rt_self_test(RtContext* ctx, uint32_t which, uint64_t n_cases, uint64_t* fai
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long), ctx->stream));
     *failures = bad;
     return RT_OK;
-}
+} RT_ABI_END_CTX(ctx)
 
-int rt_get_stats(RtContext* ctx, RtStats* out) {
+int rt_get_stats(RtContext* ctx, RtStats* out) try {
     if (!ctx || !out) return RT_ERR_INVALID;
     *out = ctx->stats;
     return RT_OK;
-}
+} RT_ABI_END_CTX(ctx)
 
-int rt_reset_stats(RtContext* ctx) {
+int rt_reset_stats(RtContext* ctx) try {
     if (!ctx) return RT_ERR_INVALID;
     if (std::getenv("RT_MI355_DEBUG_TALLIES"))
         std::fprintf(stderr, "[rt_mi355] iters %llu active_lanes %llu branch_runs %llu branch_lanes %llu shape_runs %llu shape_lanes %llu\n",
@@ -1673,6 +1692,6 @@ int rt_reset_stats(RtContext* ctx) {
     for (unsigned long long& t : ctx->tallies) t = 0;
     ctx->stats = RtStats{};
     return RT_OK;
-}
+} RT_ABI_END_CTX(ctx)
 
 }  // extern "C"

@@ -7,7 +7,7 @@
 // dealt out in contiguous pieces, every member traces its piece at the same time
 // on a host thread of its own (rt_trace_samples: per-sample radiance stays on
 // the member's GPU), then the running per-pixel sums travel from member to
-// member in sample order (hipMemcpyPeer) and each member folds its samples onto
+// member in sample order (hipMemcpyPeerAsync on the receiver's stream) and each member folds its samples onto
 // them (rt_fold_samples): the left fold of lib.rs:274-279 is the same sequence
 // of additions whatever the number of members.  No collective is needed: the
 // path has no exchange step other than this hand-over of 12 bytes per pixel.
@@ -20,6 +20,7 @@
 #include <thread>
 #include <vector>
 
+#include "abi_guard.h"
 #include "rt_mi355.h"
 
 struct RtGroup {
@@ -27,9 +28,11 @@ struct RtGroup {
     std::vector<int> device;
     std::vector<float*> d_sums;  // per member, on its GPU: 3 floats per pixel
     size_t cap_pixels = 0;
-    std::vector<float> h_sums;   // the finished sums of a pass, for rt_resolve
     std::string error;
 };
+
+// rt_context.hip: makes the context's GPU current and hands out the stream its work is enqueued on
+int rt_context_device(RtContext* ctx, hipStream_t* stream);
 
 namespace {
 
@@ -126,10 +129,19 @@ int group_sums(RtGroup* g, const RtRenderParams* p, uint32_t begin, uint32_t cou
         // the sums go from member to member in sample order
         for (uint32_t k = 0; k < n; ++k) {
             if (!mine[k]) continue;
-            if (have && k != last &&
-                hipMemcpyPeer(g->d_sums[k], g->device[k], g->d_sums[last], g->device[last], bytes) != hipSuccess) {
-                (void)hipGetLastError();
-                return group_fail(g, RT_ERR_HIP, "copy of the sums between GPUs failed");
+            if (have && k != last) {
+                // On the receiving member's own stream: rt_fold_samples enqueues its work there, so
+                // the fold is ordered after the copy (a copy between devices on the null stream is not
+                // ordered against the members' non-blocking streams, and the host does not wait for
+                // it either).  The sender's buffer is complete: its rt_fold_samples returned after
+                // draining its stream.
+                hipStream_t into = nullptr;
+                const int rs = rt_context_device(g->member[k], &into);  // makes the receiver's GPU current
+                if (rs != RT_OK) return member_fail(g, k, rs);
+                if (hipMemcpyPeerAsync(g->d_sums[k], g->device[k], g->d_sums[last], g->device[last], bytes, into) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return group_fail(g, RT_ERR_HIP, "copy of the sums between GPUs failed");
+                }
             }
             const int r = rt_fold_samples(g->member[k], p, have ? 1 : 0, g->d_sums[k], 1);
             if (r != RT_OK) return member_fail(g, k, r);
@@ -154,9 +166,17 @@ int check_group(RtGroup* g, const RtRenderParams* p) {
 
 }  // namespace
 
+int rt_abi_caught(RtGroup* g, bool out_of_memory) noexcept {
+    try {
+        if (g) g->error.assign(out_of_memory ? "out of host memory" : "internal error (an exception was caught at the C boundary)");
+    } catch (...) {
+    }
+    return out_of_memory ? RT_ERR_OOM : RT_ERR_HIP;
+}
+
 extern "C" {
 
-int rt_group_create(const int* device_ordinals, uint32_t n_devices, RtGroup** out) {
+int rt_group_create(const int* device_ordinals, uint32_t n_devices, RtGroup** out) try {
     if (!out) return RT_ERR_INVALID;
     *out = nullptr;
     g_group_error[0] = 0;
@@ -180,7 +200,7 @@ int rt_group_create(const int* device_ordinals, uint32_t n_devices, RtGroup** ou
         g->d_sums.push_back(nullptr);
     }
     // direct copies between the members' GPUs where the hardware allows them (xGMI);
-    // hipMemcpyPeer goes through host memory otherwise
+    // the copies go through host memory otherwise
     for (uint32_t a = 0; a < n_devices; ++a)
         for (uint32_t b = 0; b < n_devices; ++b) {
             int can = 0;
@@ -191,34 +211,34 @@ int rt_group_create(const int* device_ordinals, uint32_t n_devices, RtGroup** ou
         }
     *out = g;
     return RT_OK;
-}
+} RT_ABI_END_INT
 
-void rt_group_destroy(RtGroup* g) {
+void rt_group_destroy(RtGroup* g) try {
     if (!g) return;
     free_sums(g);
     for (RtContext* ctx : g->member) rt_destroy(ctx);
     delete g;
-}
+} RT_ABI_END_VOID
 
-const char* rt_group_last_error(const RtGroup* g) {
+const char* rt_group_last_error(const RtGroup* g) try {
     if (g) return g->error.c_str();
     return g_group_error[0] ? g_group_error : "null group";
-}
+} RT_ABI_END_VALUE("internal error")
 
-uint32_t rt_group_size(const RtGroup* g) { return g ? static_cast<uint32_t>(g->member.size()) : 0u; }
+uint32_t rt_group_size(const RtGroup* g) try { return g ? static_cast<uint32_t>(g->member.size()) : 0u; } RT_ABI_END_VALUE(0u)
 
-RtContext* rt_group_member(RtGroup* g, uint32_t index) { return g && index < g->member.size() ? g->member[index] : nullptr; }
+RtContext* rt_group_member(RtGroup* g, uint32_t index) try { return g && index < g->member.size() ? g->member[index] : nullptr; } RT_ABI_END_VALUE(nullptr)
 
-int rt_group_set_option(RtGroup* g, uint32_t option, uint64_t value) {
+int rt_group_set_option(RtGroup* g, uint32_t option, uint64_t value) try {
     if (!g) return RT_ERR_INVALID;
     for (size_t k = 0; k < g->member.size(); ++k) {
         const int rc = rt_set_option(g->member[k], option, value);
         if (rc != RT_OK) return member_fail(g, k, rc);
     }
     return RT_OK;
-}
+} RT_ABI_END_CTX(g)
 
-int rt_group_upload_scene(RtGroup* g, const RtSceneDesc* scene) {
+int rt_group_upload_scene(RtGroup* g, const RtSceneDesc* scene) try {
     if (!g) return RT_ERR_INVALID;
     const size_t n = g->member.size();
     std::vector<int> rc(n, RT_OK);
@@ -229,9 +249,9 @@ int rt_group_upload_scene(RtGroup* g, const RtSceneDesc* scene) {
     for (size_t k = 0; k < n; ++k)
         if (rc[k] != RT_OK) return member_fail(g, k, rc[k]);
     return RT_OK;
-}
+} RT_ABI_END_CTX(g)
 
-int rt_group_render_sums(RtGroup* g, const RtRenderParams* p, uint32_t sample_begin, uint32_t sample_count, float* sums) {
+int rt_group_render_sums(RtGroup* g, const RtRenderParams* p, uint32_t sample_begin, uint32_t sample_count, float* sums) try {
     int rc = check_group(g, p);
     if (rc != RT_OK) return rc;
     if (!sums || sample_count == 0) return group_fail(g, RT_ERR_INVALID, "bad arguments");
@@ -244,9 +264,9 @@ int rt_group_render_sums(RtGroup* g, const RtRenderParams* p, uint32_t sample_be
         return group_fail(g, RT_ERR_HIP, "copy of the sums to the host failed");
     }
     return RT_OK;
-}
+} RT_ABI_END_CTX(g)
 
-int rt_group_render(RtGroup* g, const RtRenderParams* p, uint8_t* rgb8, RtProgressFn progress, void* user) {
+int rt_group_render(RtGroup* g, const RtRenderParams* p, uint8_t* rgb8, RtProgressFn progress, void* user) try {
     int rc = check_group(g, p);
     if (rc != RT_OK) return rc;
     if (!rgb8) return group_fail(g, RT_ERR_INVALID, "null pixel buffer");
@@ -257,24 +277,23 @@ int rt_group_render(RtGroup* g, const RtRenderParams* p, uint8_t* rgb8, RtProgre
     const uint32_t n_passes = p->samples_per_pixel / chunk;
     const int running = p->incremental != 0 || p->has_continue != 0;  // lib.rs:286
     const uint32_t first_pass = p->has_continue ? p->continue_sampling : 0;
-    const size_t n_values = pixels_of(p) * 3;
-    g->h_sums.resize(n_values);
     for (uint32_t pass = 0; pass < n_passes; ++pass) {
         const uint32_t k = pass + first_pass;  // sample_iteration, lib.rs:233-234
         const uint64_t s_begin = static_cast<uint64_t>(k) * chunk;
         if (s_begin + chunk > 0xFFFFFFFFull) return group_fail(g, RT_ERR_INVALID, "sample index overflow");
-        rc = rt_group_render_sums(g, p, static_cast<uint32_t>(s_begin), chunk, g->h_sums.data());
+        size_t holder = 0;
+        rc = group_sums(g, p, static_cast<uint32_t>(s_begin), chunk, false, &holder);
         if (rc != RT_OK) return rc;
-        // mean, gamma, running average and quantisation (lib.rs:283-295) on the first member;
-        // the image is readable after every pass
-        rc = rt_resolve(g->member[0], p, g->h_sums.data(), 0, chunk, running, k, rgb8);
-        if (rc != RT_OK) return member_fail(g, 0, rc);
+        // mean, gamma, running average and quantisation (lib.rs:283-295) on the member whose GPU
+        // holds the finished sums, straight from its memory; the image is readable after every pass
+        rc = rt_resolve(g->member[holder], p, g->d_sums[holder], 1, chunk, running, k, rgb8);
+        if (rc != RT_OK) return member_fail(g, holder, rc);
         if (progress) progress(first_pass + (pass + 1) * chunk, user);  // lib.rs:238-246
     }
     return RT_OK;
-}
+} RT_ABI_END_CTX(g)
 
-int rt_group_get_stats(RtGroup* g, RtStats* out) {
+int rt_group_get_stats(RtGroup* g, RtStats* out) try {
     if (!g || !out) return RT_ERR_INVALID;
     RtStats total{};
     for (size_t k = 0; k < g->member.size(); ++k) {
@@ -292,12 +311,12 @@ int rt_group_get_stats(RtGroup* g, RtStats* out) {
     }
     *out = total;
     return RT_OK;
-}
+} RT_ABI_END_CTX(g)
 
-int rt_group_reset_stats(RtGroup* g) {
+int rt_group_reset_stats(RtGroup* g) try {
     if (!g) return RT_ERR_INVALID;
     for (RtContext* ctx : g->member) (void)rt_reset_stats(ctx);
     return RT_OK;
-}
+} RT_ABI_END_CTX(g)
 
 }  // extern "C"

@@ -68,13 +68,17 @@ def fold_in_sample_order(trace, fold, buffer, zeros, reserve, sample_begin: int,
     on, so the ranks work side by side however many rounds a pass takes.  A piece is no
     larger than what the fullest rank holds in flight (`reserve(count)` -> samples one
     `trace` call takes; `agree_min(n)` -> the minimum of n over the ranks, e.g. an all-reduce
-    with MIN — without it the ranks are taken to be configured alike).
+    with MIN.  With more than one rank it is required: `reserve` answers with what fits the
+    rank's free memory, and ranks that disagreed on the piece size would wait for transfers
+    that never come).
 
     trace(first, n) -> samples traced; fold(carry_on) -> sums; buffer() -> the tensor to
     receive into; zeros() -> sums of nothing; send(sums, dst) / recv(sums, src)."""
+    if world > 1 and agree_min is None:
+        raise ValueError("agree_min is required with more than one rank (the ranks must use one piece size)")
     per_rank = -(-sample_count // world)
     fit = reserve(per_rank) if per_rank else 1
-    if agree_min is not None and world > 1:
+    if world > 1:
         fit = int(agree_min(fit))
     if fit < 1:
         raise RuntimeError("no room for a single sample in flight")

@@ -141,10 +141,10 @@ def pass_params(params, rect, chunk: int, running: bool, k: int):
 
 def render_tiled(backend: TileBackend, image: Image, params, tile_w: int, tile_h: int, world: int = 1, rank: int = 0,
                  group_size: int = 1, reduce_in_group: Callable | None = None, end_of_pass: Callable | None = None,
-                 progress: Callable | None = None, exact_in_group: tuple[Callable, Callable] | None = None) -> None:
+                 progress: Callable | None = None, exact_in_group: tuple[Callable, Callable, Callable] | None = None) -> None:
     """Render `params` (full image) into `image`.
 
-    exact_in_group = (send, recv) or (send, recv, agree_min), instead of reduce_in_group:
+    exact_in_group = (send, recv, agree_min), instead of reduce_in_group:
     `send(sums, member)` / `recv(sums, member)` move a tile's sums to / from another member
     of this rank's group (dist.send / dist.recv to the member's rank).  The members then
     trace pieces of the tile's samples at the same time and fold them in sample order, the
@@ -163,6 +163,8 @@ def render_tiled(backend: TileBackend, image: Image, params, tile_w: int, tile_h
         raise ValueError("group size must divide the number of ranks")
     if group_size > 1 and reduce_in_group is None and exact_in_group is None:
         raise ValueError("groups of several ranks need a reduce or the exact hand-over")
+    if group_size > 1 and exact_in_group is not None and len(exact_in_group) != 3:
+        raise ValueError("exact_in_group is (send, recv, agree_min): the members must agree on one piece size")
     n_groups, group, member = world // group_size, rank // group_size, rank % group_size
     chunk, n_passes, running, first_pass = passes(params)
     grid = tile_grid(int(params.width), int(params.height), tile_w, tile_h)
@@ -179,7 +181,7 @@ def render_tiled(backend: TileBackend, image: Image, params, tile_w: int, tile_h
     image.flush()
 
 
-def _exact_tile_sums(backend, tp, begin, count, group_size, member, send, recv, agree_min=None):
+def _exact_tile_sums(backend, tp, begin, count, group_size, member, send, recv, agree_min):
     """The tile's sums by the hand-over of render_pass_exact; complete on the last member."""
     return fold_in_sample_order(lambda first, n: backend.trace(tp, first, n), lambda carry_on: backend.fold(tp, carry_on),
                                 lambda: backend.sums(tp), lambda: backend.zeros(tp), lambda n: backend.reserve(tp, n),

@@ -112,3 +112,25 @@ def test_counter_record_is_quoted_only_for_the_kernels_it_was_taken_from(monkeyp
     args = argparse.Namespace(workload="room", width=1920, height=1080, bounces=60, detail=4, fast=False)
     monkeypatch.setattr(bench, "kernel_source_hash", lambda: "not the recorded one")
     assert bench.recorded_counters(args) is None
+
+
+def test_every_exported_definition_is_exception_guarded():
+    """include/rt_mi355.h promises that nothing throws across the boundary: every definition
+    of an exported function in the device library's sources must be a function-try-block
+    closed by one of the guard macros of device/abi_guard.h."""
+    device = os.path.join(ROOT, "raytracer_amd", "csrc", "device")
+    exported = set(declared_functions("rt_mi355.h"))
+    defined = {}
+    for name in sorted(os.listdir(device)):
+        if not name.endswith(".hip"):
+            continue
+        text = open(os.path.join(device, name)).read()
+        # a definition: return type and name at the start of a line, the signature up to its opening brace
+        for m in re.finditer(r"^(?:extern \"C\" )?(?:int|void|const char\*|uint32_t|RtContext\*) (rt_[a-z0-9_]+)\(([^;{]*?)\)\s*(try\s*)?\{",
+                             text, flags=re.M | re.S):
+            if m.group(1) in exported:
+                defined[m.group(1)] = (name, bool(m.group(3)))
+        assert text.count(") try {") == len(re.findall(r"\} RT_ABI_END_(?:CTX|INT|VOID|VALUE)\b", text)), name
+    assert set(defined) == exported, sorted(exported - set(defined))
+    unguarded = sorted(n for n, (_, guarded) in defined.items() if not guarded)
+    assert not unguarded, f"exported without an exception guard: {unguarded}"

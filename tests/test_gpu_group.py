@@ -77,3 +77,43 @@ def test_group_errors():
     with RendererGroup([0]) as g:
         with pytest.raises(RtError):
             g.render_sums(s.params, 0, 2)  # no scene uploaded
+
+
+def test_hand_over_of_a_full_frame_is_ordered_before_the_fold(renderer, asset_root):
+    """A 1920x1080 frame is 24.9 MB of sums per hand-over: a copy between members that the
+    receiving member's fold did not wait for would fold onto stale sums.  Three members, one
+    sample in flight each, so that every sample's sums travel."""
+    s = scenes.room(asset_root, w=1920, h=1080, spp=6, bounces=4)
+    renderer.upload(s)
+    one = renderer.render_sums(s.params, 0, 6)
+    with RendererGroup([0, 0, 0]) as g:
+        g.upload(s)
+        g.set_option(F.RT_OPT_SAMPLES_IN_FLIGHT, 1)
+        for _ in range(2):
+            assert np.array_equal(bits(g.render_sums(s.params, 0, 6)), bits(one))
+        assert np.array_equal(g.render(s.params), renderer.render(s.params))
+
+
+def test_exceptions_inside_the_library_come_back_as_status_codes(renderer, asset_root):
+    """The boundary's guard, exercised for real: an exception raised inside an exported call
+    (RT_OPT_DEBUG_THROW) and an allocation the device cannot serve both return a status."""
+    with pytest.raises(RtError) as e:
+        renderer.set_option(F.RT_OPT_DEBUG_THROW, 1)  # std::bad_alloc inside rt_set_option
+    assert e.value.code == -4 and "memory" in str(e.value)
+    with pytest.raises(RtError) as e:
+        renderer.set_option(F.RT_OPT_DEBUG_THROW, 2)  # any other exception
+    assert e.value.code == -3
+    with RendererGroup([0, 0]) as g:
+        with pytest.raises(RtError) as e:
+            g.set_option(F.RT_OPT_DEBUG_THROW, 1)
+        assert e.value.code == -4
+    # a workspace no GPU holds: one sample of a 46000 x 46000 frame in flight is 2.1e9 paths, 270 GB of queues
+    s = scenes.room(asset_root, w=1920, h=1080, spp=4, bounces=4)
+    renderer.upload(s)
+    big = s.params.copy()
+    big.width = big.height = 46000
+    with pytest.raises(RtError) as e:
+        renderer.reserve_samples(big, 1)
+    assert e.value.code == -4
+    # the context still renders afterwards
+    assert renderer.render_sums(s.params, 0, 1).shape == (1080, 1920, 3)

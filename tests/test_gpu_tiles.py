@@ -129,6 +129,11 @@ def _hybrid_worker(rank, world, port, group_size, path, asset_root, exact=False)
         dist.recv(host, root + member)
         t.copy_(host)
 
+    def agree_min(n):
+        t = torch.tensor([n], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=mine)
+        return int(t.item())
+
     scene = scenes.room(asset_root, w=72, h=48, spp=4, bounces=8)
     p = _with(scene, 4, incremental=2)
     with Renderer(0) as r:
@@ -136,7 +141,7 @@ def _hybrid_worker(rank, world, port, group_size, path, asset_root, exact=False)
         with Image(path, 72, 48) as img:
             render_tiled(GpuTileBackend(r, torch.device("cuda", 0)), img, p, 24, 24, world=world, rank=rank,
                          group_size=group_size, reduce_in_group=reduce_in_group if group_size > 1 and not exact else None,
-                         exact_in_group=(send_to_member, recv_from_member) if exact else None, end_of_pass=dist.barrier)
+                         exact_in_group=(send_to_member, recv_from_member, agree_min) if exact else None, end_of_pass=dist.barrier)
     dist.barrier()
     dist.destroy_process_group()
 

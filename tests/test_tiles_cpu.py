@@ -156,11 +156,17 @@ def _worker(rank, world, port, group_size, path, exact=False):
     groups = [dist.new_group(list(range(g * group_size, (g + 1) * group_size))) for g in range(n_groups)]
     mine = groups[rank // group_size]
     root = (rank // group_size) * group_size
+
+    def agree_min(n):
+        t = torch.tensor([n], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=mine)
+        return int(t.item())
+
     with Image(path, 40, 28) as img:
         render_tiled(OracleTileBackend(scene), img, scene.params, 16, 16, world=world, rank=rank, group_size=group_size,
                      reduce_in_group=(lambda t: dist.reduce(t, dst=root, op=dist.ReduceOp.SUM, group=mine))
                      if group_size > 1 and not exact else None,
-                     exact_in_group=((lambda t, m: dist.send(t, root + m)), (lambda t, m: dist.recv(t, root + m))) if exact else None,
+                     exact_in_group=((lambda t, m: dist.send(t, root + m)), (lambda t, m: dist.recv(t, root + m)), agree_min) if exact else None,
                      end_of_pass=dist.barrier)
     dist.barrier()
     dist.destroy_process_group()

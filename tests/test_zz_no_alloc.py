@@ -48,6 +48,30 @@ def test_two_calls_in_a_row_equal_the_allocating_entry_point(renderer, asset_roo
     assert same(renderer.trace_rays(o2, d2), want2)
 
 
+def test_no_device_memory_is_allocated_or_released(renderer, asset_root):
+    """The property the entry point exists for: after a warm-up call, calls of different
+    sizes leave the GPU's free memory exactly where it was (hipMemGetInfo through torch)."""
+    import torch
+
+    s = scenes.room(asset_root)
+    renderer.upload(s)
+    o, d = rays(300_000, 9, [-2.9, 0.1, -3.9], [2.9, 3.1, 4.9])
+    renderer.trace_rays_noalloc(o[:1000], d[:1000])  # warm-up: code object, host-side staging of the runtime
+    torch.cuda.synchronize()
+    before = torch.cuda.mem_get_info(0)[0]
+    for n in (300_000, 17, 65_536, 300_000, 1):
+        renderer.trace_rays_noalloc(o[:n], d[:n])
+        assert torch.cuda.mem_get_info(0)[0] == before, n
+    # the allocating entry point, for contrast, grows its workspace for the larger call
+    fresh_o, fresh_d = rays(400_000, 10, [-2.9, 0.1, -3.9], [2.9, 3.1, 4.9])
+    with Renderer(0) as other:
+        other.upload(s)
+        torch.cuda.synchronize()
+        start = torch.cuda.mem_get_info(0)[0]
+        other.trace_rays(fresh_o, fresh_d)
+        assert torch.cuda.mem_get_info(0)[0] < start
+
+
 def test_deep_tree_overflows_into_the_fixed_array_and_a_second_context_shares_it(renderer):
     s = scenes.deep_chain(n=60, w=16, h=16)
     o = np.tile(np.array([[-1.0, 0.0, -3.0]], np.float32), (4096, 1))
