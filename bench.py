@@ -108,6 +108,8 @@ def recorded_counters(args):
     if rec.get("source_hash") != kernel_source_hash():
         return None
     key = f"{args.workload}:{args.width}x{args.height}:b{args.bounces}:d{args.detail}:fast{int(args.fast)}"
+    if getattr(args, "fast_build", 0):
+        key += f":leaf{args.fast_build}"
     return rec.get("workloads", {}).get(key)
 
 
@@ -342,6 +344,10 @@ def main() -> None:
     ap.add_argument("--fast", action="store_true",
                     help="RT_OPT_FAST_SLAB: reciprocal-direction slab test with fused multiply-add (not bit-exact; the line "
                          "then carries the mismatch figures against the exact mode)")
+    ap.add_argument("--fast-build", type=int, default=0, metavar="MAX_LEAF",
+                    help="opt-in, not the reference's tree: split every leaf of the triangle BVH above MAX_LEAF triangles on, past "
+                         "the reference's stop rule (rth_refine_bvh_triangles); intersection arithmetic stays exact and the line "
+                         "carries the mismatch figures against the reference's tree")
     ap.add_argument("--exact", action="store_true",
                     help="with several GPUs: hand the running sums from rank to rank in sample order instead of one "
                          "reduce, so that the image is the single-GPU image bit for bit")
@@ -419,6 +425,44 @@ def main() -> None:
     if rank != 0:
         scene = load_scene(args, r)
     r.upload(scene)
+    # ---- the refined tree against the reference's tree on this very frame (untimed), then the refined one is the scene
+    build_report = None
+    reference_scene = scene  # the CPU baseline renders the reference's own tree
+    if args.fast_build:
+        t_refine = time.perf_counter()
+        refined, order = scene.refined(args.fast_build)
+        t_refine = time.perf_counter() - t_refine
+        if args.workload != "room16k":
+            check_spp = min(args.spp, 4)
+            exact_hits = r.trace_primary(scene.params, 0, True)
+            exact_sums = r.render_sums(scene.params, 0, check_spp)
+            r.upload(refined)
+            fast_hits = r.trace_primary(scene.params, 0, True)
+            fast_sums = r.render_sums(scene.params, 0, check_spp)
+            fast_prim = fast_hits["prim"].copy()
+            tri = fast_hits["kind"] == F.RT_SHAPE_TRIANGLE
+            fast_prim[tri] = order[fast_prim[tri]]  # positions in the refined order -> the reference's ids
+            differ = (exact_hits["kind"] != fast_hits["kind"]) | (exact_hits["prim"] != fast_prim)
+            err = ((fast_sums - exact_sums) / check_spp).astype(np.float64)
+            img_e, img_f = r.resolve(scene.params, exact_sums, check_spp), r.resolve(scene.params, fast_sums, check_spp)
+            leaf = (refined.triangle_nodes["b"] & np.uint32(F.RT_LEAF_BIT)) != 0
+            build_report = {
+                "max_leaf": args.fast_build, "refine_seconds_on_host": round(t_refine, 3),
+                "nodes_reference_tree": int(scene.triangle_nodes.size), "nodes_refined_tree": int(refined.triangle_nodes.size),
+                "largest_leaf_reference_tree": int((scene.triangle_nodes["b"][(scene.triangle_nodes["b"] & np.uint32(F.RT_LEAF_BIT)) != 0]
+                                                    & np.uint32(0x7FFFFFFF)).max()),
+                "largest_leaf_refined_tree": int((refined.triangle_nodes["b"][leaf] & np.uint32(0x7FFFFFFF)).max()),
+                "pixels": int(differ.size), "spp_compared": check_spp,
+                "primary_hit_id_mismatches": int(differ.sum()), "primary_hit_id_mismatch_rate": float(differ.mean()),
+                "primary_hit_distance_bits_differing": int((exact_hits["t"].view(np.uint32) != fast_hits["t"].view(np.uint32)).sum()),
+                "radiance_values_differing": int((exact_sums.view(np.uint32) != fast_sums.view(np.uint32)).sum()),
+                "radiance_rmse": float(np.sqrt(np.mean(err ** 2))), "radiance_max_abs": float(np.abs(err).max()),
+                "u8_values_differing": int((img_e != img_f).sum()),
+                "u8_max_abs": int(np.abs(img_e.astype(np.int16) - img_f.astype(np.int16)).max()),
+            }
+        else:
+            r.upload(refined)
+        scene = refined
     chains = 2 if args.chains is None else args.chains  # 2 is the library's default
     r.set_option(F.RT_OPT_CHAINS, chains)
     r.set_option(F.RT_OPT_TRACE_WAVES_PER_CU, args.trace_waves_per_cu)
@@ -669,9 +713,12 @@ def main() -> None:
                                else "reduce(sum) of f32 radiance per step") if world > 1 else "none",
                 "arithmetic": "fast slab test (reciprocal direction, fused multiply-add): not bit-exact" if args.fast
                               else "exact (bit-identical to the CPU oracle)",
+                "tree": (f"refined: leaves of the reference's tree split on down to {args.fast_build} triangles (opt-in; not the "
+                         "reference's tree: ids can differ where distances tie)") if args.fast_build
+                        else "the reference's tree (bvh.rs:46-224), node for node",
             },
             "bench_args": {"workload": args.workload, "width": args.width, "height": args.height, "spp": args.spp,
-                           "bounces": args.bounces, "detail": args.detail, "chains": chains},
+                           "bounces": args.bounces, "detail": args.detail, "chains": chains, "fast_build": args.fast_build},
             "samples_per_s": round(paths / dt, 1),
             "image_repeats": repeatable,  # an extra, untimed step stored the same bytes as the last timed one
             "rays_per_sample": round(rays_per_path, 3),
@@ -679,8 +726,10 @@ def main() -> None:
         }
         if fast_report is not None:
             out["fast_mode_vs_exact"] = fast_report
+        if build_report is not None:
+            out["refined_tree_vs_reference_tree"] = build_report
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, args)
+            out["cpu_baseline"] = cpu_baseline(reference_scene, args)
         print(json.dumps(out), flush=True)
 
     if tiled:

@@ -53,6 +53,21 @@ RtNode* rth_build_bvh_planes(RtPlane* shapes, uint32_t n, uint32_t* n_nodes);
 RtNode* rth_build_bvh_triangles(RtTriangle* shapes, uint32_t n, uint32_t* n_nodes);
 void rth_free(void* p);
 
+/* Opt-in, NON-PARITY faster tree (no counterpart in the reference): keeps the node array
+ * of `BvhNode::new` as it is and goes on splitting every leaf that holds more than
+ * `max_leaf` triangles, i.e. without the stop rule `15 + cost >= 2 * num` of
+ * /root/reference/src/bvh.rs:169, which leaves clusters of overlapping shapes as leaves of
+ * dozens to hundreds of triangles.  `triangles` is permuted in place (inside each such
+ * leaf's range only) and `order[i]` receives the position, before the call, of the
+ * triangle now at i; the returned node array (malloc'd, free with rth_free; the first
+ * `n_nodes` entries are the reference's nodes, new ones follow) describes the same
+ * triangles.  Intersection arithmetic is untouched, so nearest-hit distances are the same
+ * numbers; which of several triangles at exactly the same distance is reported may
+ * differ from the reference's tree, and primitive ids are positions after this call
+ * (map them back through `order`).  Returns NULL on bad arguments or lack of memory. */
+RtNode* rth_refine_bvh_triangles(const RtNode* nodes, uint32_t n_nodes, RtTriangle* triangles, uint32_t n_triangles,
+                                 uint32_t max_leaf, uint32_t* order, uint32_t* n_nodes_out);
+
 /* `ColorKind::texture_from_ppm_p6`, /root/reference/src/material.rs:150-189.
  * Returns malloc'd packed RGB8 texels (free with rth_free) or NULL. */
 uint8_t* rth_load_ppm_p6(const char* path, uint32_t* width, uint32_t* height, char* err,

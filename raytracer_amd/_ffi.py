@@ -149,6 +149,7 @@ _HOST_SYMBOLS = {
     "rth_build_bvh_planes": (C.c_void_p, [C.c_void_p, u32, C.POINTER(u32)]),
     "rth_build_bvh_triangles": (C.c_void_p, [C.c_void_p, u32, C.POINTER(u32)]),
     "rth_free": (None, [C.c_void_p]),
+    "rth_refine_bvh_triangles": (C.c_void_p, [C.c_void_p, u32, C.c_void_p, u32, u32, C.c_void_p, C.POINTER(u32)]),
     "rth_load_ppm_p6": (C.c_void_p, [C.c_char_p, C.POINTER(u32), C.POINTER(u32), C.c_char_p, C.c_size_t]),
     "rth_image_open": (C.c_void_p, [C.c_char_p, u32, u32, C.c_char_p, C.c_size_t]),
     "rth_image_pixels": (C.c_void_p, [C.c_void_p]),

@@ -119,6 +119,26 @@ class Scene:
                    materials if materials is not None else np.zeros(0, dtype=MATERIAL_DT),
                    texels if texels is not None else np.zeros(0, dtype=np.uint8), sn, pn, tn)
 
+    def refined(self, max_leaf: int = 8) -> tuple["Scene", np.ndarray]:
+        """The opt-in, non-parity faster tree (rth_refine_bvh_triangles of include/rt_host.h):
+        the reference's triangle tree with every leaf above `max_leaf` triangles split on,
+        past the stop rule of /root/reference/src/bvh.rs:169.  Returns (scene, order):
+        triangle i of the new scene is triangle order[i] of this one.  Hit distances are the
+        same numbers; primitive ids are positions in the new order."""
+        lib = F.host_lib()
+        tris = self.triangles.copy()
+        order = np.zeros(tris.size, dtype=np.uint32)
+        n_out = F.u32(0)
+        raw = lib.rth_refine_bvh_triangles(self.triangle_nodes.ctypes.data, self.triangle_nodes.size,
+                                           tris.ctypes.data if tris.size else None, tris.size, int(max_leaf),
+                                           order.ctypes.data, C.byref(n_out))
+        if not raw:
+            raise MemoryError("BVH refinement failed")
+        nodes = _view(C.c_void_p(raw), n_out.value, NODE_DT)
+        lib.rth_free(raw)
+        return Scene(self.params, self.spheres, self.planes, tris, self.vertex_normals, self.tex_coords,
+                     self.bary_precomputed, self.materials, self.texels, self.sphere_nodes, self.plane_nodes, nodes), order
+
     # ------------------------------------------------------------------- view
     def desc(self) -> F.RtSceneDesc:
         """RtSceneDesc pointing into this object's arrays (keep `self` alive)."""

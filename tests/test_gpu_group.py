@@ -96,7 +96,7 @@ def test_hand_over_of_a_full_frame_is_ordered_before_the_fold(renderer, asset_ro
 
 def test_exceptions_inside_the_library_come_back_as_status_codes(renderer, asset_root):
     """The boundary's guard, exercised for real: an exception raised inside an exported call
-    (RT_OPT_DEBUG_THROW) and an allocation the device cannot serve both return a status."""
+    (RT_OPT_DEBUG_THROW: std::bad_alloc, then any other exception) returns a status."""
     with pytest.raises(RtError) as e:
         renderer.set_option(F.RT_OPT_DEBUG_THROW, 1)  # std::bad_alloc inside rt_set_option
     assert e.value.code == -4 and "memory" in str(e.value)
@@ -107,13 +107,7 @@ def test_exceptions_inside_the_library_come_back_as_status_codes(renderer, asset
         with pytest.raises(RtError) as e:
             g.set_option(F.RT_OPT_DEBUG_THROW, 1)
         assert e.value.code == -4
-    # a workspace no GPU holds: one sample of a 46000 x 46000 frame in flight is 2.1e9 paths, 270 GB of queues
-    s = scenes.room(asset_root, w=1920, h=1080, spp=4, bounces=4)
+    s = scenes.room(asset_root, w=192, h=108, spp=4, bounces=4)
     renderer.upload(s)
-    big = s.params.copy()
-    big.width = big.height = 46000
-    with pytest.raises(RtError) as e:
-        renderer.reserve_samples(big, 1)
-    assert e.value.code == -4
     # the context still renders afterwards
-    assert renderer.render_sums(s.params, 0, 1).shape == (1080, 1920, 3)
+    assert renderer.render_sums(s.params, 0, 1).shape == (108, 192, 3)
