@@ -103,6 +103,9 @@ unsafe extern "C" {
         ctx: *mut RtContext, shapes: *mut RtSphere, n: u32, nodes: *mut *mut RtNode, n_nodes: *mut u32,
     ) -> c_int;
     pub fn rt_free(p: *mut c_void);
+    /// Page-locked pixel buffers (full-rate copies to and from the GPU); release with `rt_host_free`.
+    pub fn rt_host_alloc(bytes: usize) -> *mut c_void;
+    pub fn rt_host_free(p: *mut c_void);
     pub fn rt_abi_version() -> u32;
     pub fn rt_set_option(ctx: *mut RtContext, option: u32, value: u64) -> c_int;
     pub fn rt_render_sums(

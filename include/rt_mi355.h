@@ -393,7 +393,20 @@ void rt_free(void* p);
  * (every binary32 value in its range; `n_cases` is ignored). */
 #define RT_SELF_TEST_DIVISION 1u
 #define RT_SELF_TEST_RECIPROCAL 2u
+#define RT_SELF_TEST_UNIT_BYTE 3u /* texel byte / 255 without a division: all 256 bytes against `/` */
 int rt_self_test(RtContext* ctx, uint32_t which, uint64_t n_cases, uint64_t* failures);
+
+/* Page-locked host memory for pixel buffers handed to rt_render / rt_resolve /
+ * rt_group_render (no counterpart in the reference, whose image is its memory
+ * mapping, /root/reference/src/mmap.rs:41-77).  Copies between such a buffer and
+ * the GPU run at the full rate of the host link; from ordinary pageable memory —
+ * the mapping itself included — the runtime stages them through small buffers of
+ * its own at a fraction of that.  Worth it for tiles of hundreds of megabytes
+ * (the tile loop of a 16K image: copy the tile's rows from the mapping into such
+ * a buffer, render, copy back).  NULL when the memory cannot be had; release
+ * with rt_host_free.  Needs a GPU in the process, no context. */
+void* rt_host_alloc(size_t bytes);
+void rt_host_free(void* p);
 
 int rt_get_stats(RtContext* ctx, RtStats* out);
 int rt_reset_stats(RtContext* ctx);

@@ -121,6 +121,8 @@ _DEVICE_SYMBOLS = {
     "rt_build_bvh_triangles": (C.c_int, [C.c_void_p, C.c_void_p, u32, C.POINTER(C.c_void_p), C.POINTER(u32)]),
     "rt_build_bvh_spheres": (C.c_int, [C.c_void_p, C.c_void_p, u32, C.POINTER(C.c_void_p), C.POINTER(u32)]),
     "rt_free": (None, [C.c_void_p]),
+    "rt_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "rt_host_free": (None, [C.c_void_p]),
     "rt_self_test": (C.c_int, [C.c_void_p, u32, u64, C.POINTER(u64)]),
     "rt_get_stats": (C.c_int, [C.c_void_p, C.POINTER(RtStats)]),
     "rt_reset_stats": (C.c_int, [C.c_void_p]),

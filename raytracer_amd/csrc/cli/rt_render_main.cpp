@@ -108,6 +108,19 @@ struct Accumulator {
     }
 };
 
+// A tile's pixel bytes: rt_host_alloc'd if possible, heap memory otherwise.
+struct PixelBuffer {
+    explicit PixelBuffer(size_t bytes) : pinned(static_cast<uint8_t*>(rt_host_alloc(bytes))) {
+        if (!pinned) heap.resize(bytes);
+    }
+    ~PixelBuffer() { rt_host_free(pinned); }
+    PixelBuffer(const PixelBuffer&) = delete;
+    PixelBuffer& operator=(const PixelBuffer&) = delete;
+    uint8_t* data() { return pinned ? pinned : heap.data(); }
+    uint8_t* pinned;
+    std::vector<uint8_t> heap;
+};
+
 int main(int argc, char** argv) {
     const std::string scene_path = argc > 1 ? argv[1] : "scene";
     const std::string out_path = argc > 2 ? argv[2] : "target/out.ppm";
@@ -227,7 +240,10 @@ int main(int argc, char** argv) {
         const uint32_t n_passes = params.samples_per_pixel / chunk;
         const bool running = params.incremental != 0 || params.has_continue != 0;
         const uint32_t first_pass = params.has_continue ? params.continue_sampling : 0;
-        std::vector<uint8_t> tile(static_cast<size_t>(std::min(tile_edge, params.width)) * std::min(tile_edge, params.height) * 3);
+        // the tile's bytes go through page-locked memory when it can be had: copies to and from
+        // the GPU at the full rate of the host link (ordinary memory otherwise)
+        const size_t tile_bytes = static_cast<size_t>(std::min(tile_edge, params.width)) * std::min(tile_edge, params.height) * 3;
+        PixelBuffer tile(tile_bytes);
         for (uint32_t pass = 0; pass < n_passes && rc == RT_OK; ++pass) {
             // one pass of one tile = a render of `chunk` samples that resumes at pass k
             RtRenderParams tp = params;

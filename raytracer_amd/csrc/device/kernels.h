@@ -862,9 +862,22 @@ __global__ void k_hit_records(const float* hit_t, const uint32_t* hit_id, HitOut
 
 // ------------------------------------------------------------------- shade
 
+// byte / 255.0 (vec3.rs:515-520: u8 -> f32, then true division) for byte k of a texel word,
+// without a division and without a table: with z = RN(1/255), q0 = RN(b*z) is one of the two
+// neighbours of b/255, r = b - 255*q0 is exact in one FMA, and RN(q0 + r*z) is the correctly
+// rounded quotient (Markstein's correction; k_selftest_unit compares all 256 bytes with `/`).
+// v_cvt_f32_ubyteK takes the byte straight out of the word.
+template <int K>
+__device__ __forceinline__ float unit_of_byte(uint32_t texel) {
+    const float b = static_cast<float>((texel >> (8 * K)) & 255u);
+    constexpr float z = 1.0f / 255.0f;
+    const float q0 = b * z;
+    const float r = __builtin_fmaf(-255.0f, q0, b);
+    return __builtin_fmaf(r, z, q0);
+}
+
 // material.rs:192-239
-__device__ __forceinline__ F3 color_sample(const DScene& sc, const DMaterial& m, float u_in, float v_in,
-                                           const float* unit_of_byte) {
+__device__ __forceinline__ F3 color_sample(const DScene& sc, const DMaterial& m, float u_in, float v_in) {
     if (m.color_kind == 0) return f3(m.rgb);
     float c[2] = {u_in, v_in};
 #pragma unroll
@@ -892,10 +905,9 @@ __device__ __forceinline__ F3 color_sample(const DScene& sc, const DMaterial& m,
     }
     const uint32_t* tex = in_global(sc.texels) + m.tex_first;
     const size_t tiles_per_row = (static_cast<size_t>(m.tex_width) + (kTexTileW - 1u)) / kTexTileW;
-    // byte -> byte/255 (vec3.rs:515-520) through a 256-entry table of exact quotients
     auto texel = [&](uint32_t x, uint32_t y) {
         const uint32_t t = tex[((y / kTexTileH) * tiles_per_row + x / kTexTileW) * kTexTileTexels + (y % kTexTileH) * kTexTileW + x % kTexTileW];
-        return f3(unit_of_byte[t & 255u], unit_of_byte[(t >> 8) & 255u], unit_of_byte[(t >> 16) & 255u]);
+        return f3(unit_of_byte<0>(t), unit_of_byte<1>(t), unit_of_byte<2>(t));
     };
     const F3 c00 = texel(i0[0], i0[1]), c01 = texel(i0[0], i1[1]);
     const F3 c10 = texel(i1[0], i0[1]), c11 = texel(i1[0], i1[1]);
@@ -921,9 +933,9 @@ struct ShadeArgs {
 // surface attributes of shapes.rs:91-99,157-165,264-326 inlined.  A path that
 // ends here leaves its radiance in result[slot]; for one that goes on (returns
 // true) the next ray's origin and direction, the throughput, the generator state
-// and the result slot are handed back.  `unit_of_byte`: 256 floats, byte/255.
+// and the result slot are handed back.
 __device__ __forceinline__ bool shade_entry(const DScene& scene, const DQueue& cur, uint32_t i, float4* result, int last_bounce,
-                                            const float* unit_of_byte, F3& no, F3& nd, F3& thr, unsigned long long& rng,
+                                            F3& no, F3& nd, F3& thr, unsigned long long& rng,
                                             uint32_t& slot, unsigned long long& hits) {
     bool alive = false;  // continues into the next bounce
     const F3 o = stream_load(&cur.origin[i]), d = stream_load(&cur.direction[i]);
@@ -1032,7 +1044,7 @@ __device__ __forceinline__ bool shade_entry(const DScene& scene, const DQueue& c
         if (what == 1) {
             in_global(result)[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // lib.rs:359-362
         } else {
-            thr = thr * color_sample(scene, m, uv0, uv1, unit_of_byte);
+            thr = thr * color_sample(scene, m, uv0, uv1);
             if (what == 2 || last_bounce) {
                 // a light ends the path; so does the bounce limit, which
                 // returns the throughput reached so far (lib.rs:313,374)
@@ -1063,11 +1075,8 @@ __device__ __forceinline__ void store_survivor(const DScene& scene, const DQueue
 
 // shade_entry over a whole queue; the surviving paths are compacted into `next`.
 __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
-    __shared__ float s_unit[256];      // byte/255, all 256 quotients by true division
     __shared__ uint32_t s_wave_live[4];
     __shared__ uint32_t s_block_base;
-    s_unit[threadIdx.x] = static_cast<float>(threadIdx.x) / 255.0f;
-    __syncthreads();
     const uint32_t n = *a.n_cur;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -1079,7 +1088,7 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
         F3 no = f3(0, 0, 0), nd = f3(0, 0, 0), thr = f3(0, 0, 0);
         unsigned long long rng = 0;
         uint32_t slot = 0;
-        const bool alive = i < n && shade_entry(a.scene, a.cur, i, a.result, a.last_bounce, s_unit, no, nd, thr, rng, slot, my_hits);
+        const bool alive = i < n && shade_entry(a.scene, a.cur, i, a.result, a.last_bounce, no, nd, thr, rng, slot, my_hits);
         // compaction: one atomic per workgroup and round; survivors keep their order
         const unsigned long long live = __ballot(alive);
         if (lane == 0) s_wave_live[wave] = __popcll(live);
@@ -1117,7 +1126,7 @@ __global__ void __launch_bounds__(256) k_shade(ShadeArgs a) {
 //
 // For scenes whose only traversed family is the triangles (spheres and planes
 // absent or scanned where rays are created).  Dynamic LDS: the traversal
-// kernel's layout, then 256 floats (byte / 255).
+// kernel's layout.
 
 // What the shading half of k_path needs, kept in device memory rather than in the kernel's
 // argument block: arguments are fetched into scalar registers at the kernel's entry and would
@@ -1174,12 +1183,9 @@ __global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num
     const uint32_t gtid = blockIdx.x * (kTraceBlock * WAVES) + threadIdx.x;
     const uint32_t cache_nodes = a.t.cache_nodes;
     {
-        float* const s_unit = reinterpret_cast<float*>(s_raw + static_cast<size_t>(cache_nodes) * sizeof(DNode) +
-                                                       WAVES * trace_lds_per_wave(a.t.lds_slots));
         const float4* src = reinterpret_cast<const float4*>(a.t.fam.nodes);
         for (uint32_t k = threadIdx.x; k < cache_nodes * 4u; k += kTraceBlock * WAVES)
             s_nodes[(k & 3u) * cache_nodes + (k >> 2)] = src[k];
-        for (uint32_t k = threadIdx.x; k < 256u; k += kTraceBlock * WAVES) s_unit[k] = static_cast<float>(k) / 255.0f;
         __syncthreads();
     }
     // this wave's paths: blocks g, g + W, g + 2W, ... of the batch's blocks of 64 (see k_raygen), stored from
@@ -1217,8 +1223,6 @@ __global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num
             const DScene scene = read_const(&pc->scene);
             const DQueue cur = read_const(&pc->q[c]), next = read_const(&pc->q[c ^ 1u]);
             float4* const result = pc->result;
-            const float* s_unit = reinterpret_cast<const float*>(s_raw + static_cast<size_t>(cache_nodes) * sizeof(DNode) +
-                                                                 WAVES * trace_lds_per_wave(a.t.lds_slots));
             const int last_bounce = b + 1 == a.max_bounces;
             uint32_t n_out = 0;
             for (uint32_t blk = 0; blk < n; blk += kTraceBlock) {
@@ -1226,7 +1230,7 @@ __global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num
                 F3 no = f3(0, 0, 0), nd = f3(0, 0, 0), thr = f3(0, 0, 0);
                 unsigned long long rng = 0;
                 uint32_t slot = 0;
-                const bool alive = i < n && shade_entry(scene, cur, at + i, result, last_bounce, s_unit, no, nd, thr, rng, slot, my_hits);
+                const bool alive = i < n && shade_entry(scene, cur, at + i, result, last_bounce, no, nd, thr, rng, slot, my_hits);
                 const unsigned long long live = __ballot(alive);
                 if (alive) store_survivor(scene, next, at + n_out + bits_below_lane(live), no, nd, thr, rng, slot, nullptr);
                 n_out += __popcll(live);
@@ -1350,6 +1354,19 @@ __global__ void k_selftest_division(unsigned long long seed, uint32_t per_thread
         const bool ok1 = __float_as_uint(q.y) == __float_as_uint(w1) || (q.y == 0.0f && w1 == 0.0f);
         bad += (ok0 ? 0u : 1u) + (ok1 ? 0u : 1u);
     }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+// Self-test of unit_of_byte: all 256 bytes, in each of a word's three byte positions, against
+// `static_cast<float>(b) / 255.0f`.  Counts the differences.
+__global__ void k_selftest_unit(unsigned long long* mismatches) {
+    const uint32_t b = threadIdx.x & 255u;
+    const float want = static_cast<float>(b) / 255.0f;
+    const uint32_t noise = 0xA5u ^ b;  // other bytes of the word must not matter
+    unsigned long long bad = 0;
+    bad += __float_as_uint(unit_of_byte<0>(b | (noise << 8) | (noise << 16) | (noise << 24))) != __float_as_uint(want);
+    bad += __float_as_uint(unit_of_byte<1>((b << 8) | noise | (noise << 16) | (noise << 24))) != __float_as_uint(want);
+    bad += __float_as_uint(unit_of_byte<2>((b << 16) | noise | (noise << 8) | (noise << 24))) != __float_as_uint(want);
     if (bad) atomicAdd(mismatches, bad);
 }
 

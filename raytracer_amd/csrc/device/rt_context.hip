@@ -618,7 +618,7 @@ int launch_path_variant(RtContext* ctx, PathArgs a, const FrameArgs& f, uint32_t
     const void* fn = reinterpret_cast<const void*>(&k_path<WAVES, FASTSLAB>);
     const int block = kTraceBlock * WAVES;
     a.t.cache_nodes = std::min(ctx->tune_cache_nodes, ctx->fam[RT_SHAPE_TRIANGLE].n_branches);
-    const size_t lds = static_cast<size_t>(a.t.cache_nodes) * sizeof(DNode) + WAVES * trace_lds_per_wave(a.t.lds_slots) + 256 * sizeof(float);
+    const size_t lds = static_cast<size_t>(a.t.cache_nodes) * sizeof(DNode) + WAVES * trace_lds_per_wave(a.t.lds_slots);
     const RtContext::Occupancy* it = nullptr;
     for (const RtContext::Occupancy& o : ctx->trace_occupancy)
         if (o.fn == fn && o.lds == lds) it = &o;
@@ -1654,15 +1654,18 @@ int rt_trace_rays_noalloc(RtContext* ctx, const float* origins, const float* dir
 
 int rt_self_test(RtContext* ctx, uint32_t which, uint64_t n_cases, uint64_t* failures) try {
     if (!ctx || !failures) return RT_ERR_INVALID;
-    if (which != RT_SELF_TEST_DIVISION && which != RT_SELF_TEST_RECIPROCAL) return fail(ctx, RT_ERR_INVALID, "unknown self test");
+    if (which != RT_SELF_TEST_DIVISION && which != RT_SELF_TEST_RECIPROCAL && which != RT_SELF_TEST_UNIT_BYTE)
+        return fail(ctx, RT_ERR_INVALID, "unknown self test");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, sizeof(unsigned long long), ctx->stream));
     const uint32_t threads = 256u * 1024u;
     if (which == RT_SELF_TEST_DIVISION) {
         const uint32_t per_thread = static_cast<uint32_t>(std::min<uint64_t>((n_cases / 2 + threads - 1) / threads, 1u << 20));
         hipLaunchKernelGGL(k_selftest_division, dim3(threads / 256), dim3(256), 0, ctx->stream, 0x1234567ull, per_thread, ctx->d_stats);
-    } else {
+    } else if (which == RT_SELF_TEST_RECIPROCAL) {
         hipLaunchKernelGGL(k_selftest_reciprocal, dim3(threads / 256), dim3(256), 0, ctx->stream, ctx->d_stats);
+    } else {
+        hipLaunchKernelGGL(k_selftest_unit, dim3(1), dim3(256), 0, ctx->stream, ctx->d_stats);
     }
     HIP_TRY(ctx, hipGetLastError());
     unsigned long long bad = 0;
@@ -1672,6 +1675,20 @@ int rt_self_test(RtContext* ctx, uint32_t which, uint64_t n_cases, uint64_t* fai
     *failures = bad;
     return RT_OK;
 } RT_ABI_END_CTX(ctx)
+
+// Page-locked host memory, usable with every GPU of the process.
+void* rt_host_alloc(size_t bytes) try {
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+} RT_ABI_END_VALUE(nullptr)
+
+void rt_host_free(void* p) try {
+    if (p) (void)hipHostFree(p);
+} RT_ABI_END_VOID
 
 int rt_get_stats(RtContext* ctx, RtStats* out) try {
     if (!ctx || !out) return RT_ERR_INVALID;

@@ -208,6 +208,13 @@ class Renderer:
         self._check(self._lib.rt_self_test(self._ctx, 2, 0, C.byref(bad)))
         return int(bad.value)
 
+    def self_test_unit_byte(self) -> int:
+        """Number of (byte, position in the texel word) cases whose texel conversion differs
+        from `byte / 255.0f`; 0 on a correct build."""
+        bad = F.u64(0)
+        self._check(self._lib.rt_self_test(self._ctx, 3, 0, C.byref(bad)))
+        return int(bad.value)
+
     # ------------------------------------------------------------------- stats
     def stats(self) -> dict:
         s = F.RtStats()

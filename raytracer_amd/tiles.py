@@ -48,8 +48,11 @@ class Image:
         buf = (C.c_uint8 * n).from_address(self._lib.rth_image_pixels(self._h))
         return np.frombuffer(buf, dtype=np.uint8).reshape(self.height, self.width, 3)
 
-    def read_tile(self, x: int, y: int, w: int, h: int) -> np.ndarray:
-        out = np.empty((h, w, 3), dtype=np.uint8)
+    def read_tile(self, x: int, y: int, w: int, h: int, out: np.ndarray | None = None) -> np.ndarray:
+        """The tile's bytes, into `out` (a C-contiguous (h, w, 3) uint8 array) when given."""
+        if out is None:
+            out = np.empty((h, w, 3), dtype=np.uint8)
+        assert out.dtype == np.uint8 and out.shape == (h, w, 3) and out.flags.c_contiguous
         if self._lib.rth_image_read_tile(self._h, x, y, w, h, out.ctypes.data) != 0:
             raise ValueError("tile outside the image")
         return out
@@ -103,11 +106,16 @@ def passes(params) -> tuple[int, int, bool, int]:
 
 class TileBackend(Protocol):
     """What the driver needs from a renderer.  `sums` objects are whatever the
-    group's reduce works on (torch tensors); only the backend looks inside."""
+    group's reduce works on (torch tensors); only the backend looks inside.
+    A backend may also offer `pixel_buffer(h, w)` -> an (h, w, 3) uint8 array that is cheap
+    for it to read and write (page-locked memory for a GPU); the tile loop then keeps
+    three of them going round: one being filled from the file, one being rendered,
+    one being written back."""
 
-    def render_tile_pass(self, params, old: np.ndarray | None) -> np.ndarray:
+    def render_tile_pass(self, params, old: np.ndarray | None, out: np.ndarray | None = None) -> np.ndarray:
         """All of one pass of one tile on this rank alone: `params` describes the
-        tile and the pass (see pass_params); returns the tile's new bytes."""
+        tile and the pass (see pass_params); returns the tile's new bytes (written over
+        `old`, or into `out` when given: buffers of the tile loop's pool)."""
 
     def render_sums(self, params, sample_begin: int, sample_count: int): ...
 
@@ -181,6 +189,41 @@ def render_tiled(backend: TileBackend, image: Image, params, tile_w: int, tile_h
     image.flush()
 
 
+class _BufferPool:
+    """Up to `n` pixel buffers of the backend's kind (see TileBackend), re-used from tile to
+    tile; a tile smaller than a buffer gets a view of its start.  Without `pixel_buffer` on
+    the backend every request is a fresh numpy array."""
+
+    def __init__(self, backend, n: int):
+        self._make = getattr(backend, "pixel_buffer", None)
+        self._free: list[np.ndarray] = []
+        self._bases: dict[int, np.ndarray] = {}
+        self._left = n
+
+    def take(self, h: int, w: int) -> np.ndarray:
+        if self._make is None:
+            return np.empty((h, w, 3), dtype=np.uint8)
+        need = h * w * 3
+        for i, b in enumerate(self._free):
+            if b.size >= need:
+                base = self._free.pop(i)
+                break
+        else:
+            if self._left == 0 and self._free:
+                self._free.pop(0)  # too small for this tile: let it go
+                self._left += 1
+            self._left -= 1
+            base = self._make(h, w).reshape(-1)
+        view = base[:need].reshape(h, w, 3)
+        self._bases[view.ctypes.data] = base
+        return view
+
+    def give_back(self, tile: np.ndarray) -> None:
+        base = self._bases.pop(tile.ctypes.data, None)
+        if base is not None:
+            self._free.append(base)
+
+
 def _exact_tile_sums(backend, tp, begin, count, group_size, member, send, recv, agree_min):
     """The tile's sums by the hand-over of render_pass_exact; complete on the last member."""
     return fold_in_sample_order(lambda first, n: backend.trace(tp, first, n), lambda carry_on: backend.fold(tp, carry_on),
@@ -194,15 +237,24 @@ def _render_passes(backend, image, params, grid, mine, copier, chunk, n_passes, 
         k = p + first_pass
         if group_size == 1:
             rects = [grid[ti] for ti in mine]
-            ahead = copier.submit(image.read_tile, *rects[0]) if running and rects else None
+            pool = _BufferPool(backend, 3)
+
+            def read(rect):
+                return image.read_tile(*rect, out=pool.take(rect[3], rect[2]))
+
+            def write(rect, tile):
+                image.write_tile(rect[0], rect[1], tile)
+                pool.give_back(tile)
+
+            ahead = copier.submit(read, rects[0]) if running and rects else None
             writing = None
             for n, rect in enumerate(rects):
-                old = ahead.result() if ahead is not None else None
-                ahead = copier.submit(image.read_tile, *rects[n + 1]) if running and n + 1 < len(rects) else None
-                new = backend.render_tile_pass(pass_params(params, rect, chunk, running, k), old)
-                if writing is not None:
+                if writing is not None:  # (before the next read is queued: the pool's third buffer comes back with it)
                     writing.result()
-                writing = copier.submit(image.write_tile, rect[0], rect[1], new)
+                old = ahead.result() if ahead is not None else pool.take(rect[3], rect[2])
+                ahead = copier.submit(read, rects[n + 1]) if running and n + 1 < len(rects) else None
+                new = backend.render_tile_pass(pass_params(params, rect, chunk, running, k), old if running else None, out=old)
+                writing = copier.submit(write, rect, new)
             if writing is not None:
                 writing.result()
         for ti in (mine if group_size > 1 else ()):
@@ -230,6 +282,19 @@ def _render_passes(backend, image, params, grid, mine, copier, chunk, n_passes, 
             progress(first_pass + (p + 1) * chunk)
 
 
+class _Pinned:
+    """Owner of one rt_host_alloc block."""
+
+    def __init__(self, lib, ptr):
+        self._lib, self._ptr = lib, ptr
+
+    def __del__(self):
+        try:
+            self._lib.rt_host_free(self._ptr)
+        except Exception:
+            pass
+
+
 class GpuTileBackend:
     """TileBackend over librt_mi355.so.  Radiance sums stay on the GPU: the
     library writes them into a torch CUDA tensor (what RCCL reduces) through its
@@ -246,10 +311,30 @@ class GpuTileBackend:
         self.renderer = renderer
         self.device = device
         self._buffer = None
+        self._pinned = []
 
-    def render_tile_pass(self, params, old):
+    def pixel_buffer(self, h: int, w: int) -> np.ndarray:
+        """An (h, w, 3) uint8 array in page-locked host memory (rt_host_alloc): tile copies to and
+        from the GPU then run at the full rate of the host link instead of being staged by the
+        runtime.  Ordinary memory if the allocation is refused."""
+        lib = F.device_lib()
+        n = h * w * 3
+        ptr = lib.rt_host_alloc(n)
+        if not ptr:
+            return np.empty((h, w, 3), dtype=np.uint8)
+        keeper = _Pinned(lib, ptr)
+        arr = np.frombuffer((C.c_uint8 * n).from_address(ptr), dtype=np.uint8).reshape(h, w, 3)
+        self._pinned.append((arr, keeper))  # released with the backend
+        return arr
+
+    def render_tile_pass(self, params, old, out=None):
         h, w = params.tile_shape()
-        rgb8 = np.zeros((h, w, 3), dtype=np.uint8) if old is None else np.ascontiguousarray(old)
+        if old is not None:
+            rgb8 = np.ascontiguousarray(old)
+        elif out is not None:
+            rgb8 = out
+        else:
+            rgb8 = np.zeros((h, w, 3), dtype=np.uint8)
         return self.renderer.render(params, rgb8)
 
     def _tensor(self, params):

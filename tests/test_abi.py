@@ -93,7 +93,7 @@ def test_every_declared_entry_point_is_bound_in_python_and_in_the_rust_binding()
     import re
 
     header = open(os.path.join(ROOT, "include", "rt_mi355.h")).read()
-    declared = set(re.findall(r"^(?:int|void|uint32_t|const char\*|RtContext\*)\s+(rt_\w+)\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|void\*?|uint32_t|const char\*|RtContext\*)\s+(rt_\w+)\(", header, flags=re.M))
     assert {"rt_create", "rt_render", "rt_trace_rays_noalloc", "rt_get_stats", "rt_group_render", "rt_group_member"} <= declared
     assert declared == set(F._DEVICE_SYMBOLS)
     rust = open(os.path.join(ROOT, "bindings", "rt_mi355.rs")).read()
@@ -126,7 +126,7 @@ def test_every_exported_definition_is_exception_guarded():
             continue
         text = open(os.path.join(device, name)).read()
         # a definition: return type and name at the start of a line, the signature up to its opening brace
-        for m in re.finditer(r"^(?:extern \"C\" )?(?:int|void|const char\*|uint32_t|RtContext\*) (rt_[a-z0-9_]+)\(([^;{]*?)\)\s*(try\s*)?\{",
+        for m in re.finditer(r"^(?:extern \"C\" )?(?:int|void\*?|const char\*|uint32_t|RtContext\*) (rt_[a-z0-9_]+)\(([^;{]*?)\)\s*(try\s*)?\{",
                              text, flags=re.M | re.S):
             if m.group(1) in exported:
                 defined[m.group(1)] = (name, bool(m.group(3)))

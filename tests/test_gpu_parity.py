@@ -322,6 +322,11 @@ def test_triangle_reciprocal_is_ieee_division(renderer):
     assert renderer.self_test_reciprocal() == 0
 
 
+def test_texel_conversion_is_the_true_quotient(renderer):
+    # exhaustive: 256 bytes in each of the three positions of a texel word, against byte / 255.0f
+    assert renderer.self_test_unit_byte() == 0
+
+
 def test_extreme_coordinates_take_the_plain_division_path(renderer):
     # coordinates outside the regime of the shared-reciprocal division (tiny, huge,
     # and directions with tiny or zero components) must still match exactly

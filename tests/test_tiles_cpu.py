@@ -61,12 +61,22 @@ def test_image_tiles_round_trip(tmp_path):
 class OracleTileBackend:
     """TileBackend over the CPU oracle (test stand-in for GpuTileBackend)."""
 
-    def __init__(self, scene):
+    def __init__(self, scene, pooled=False):
         self.scene = scene
+        self.made = []  # buffers handed to the tile loop's pool
+        if pooled:
+            self.pixel_buffer = self._pixel_buffer
 
-    def render_tile_pass(self, params, old):
+    def _pixel_buffer(self, h, w):
+        self.made.append(np.full((h, w, 3), 0xCD, dtype=np.uint8))  # stale bytes: every use must overwrite them
+        return self.made[-1]
+
+    def render_tile_pass(self, params, old, out=None):
         from oracle import binding as O
         rgb8, _ = O.render(self.scene, params, None if old is None else np.ascontiguousarray(old))
+        if out is not None:
+            out[...] = rgb8
+            return out
         return rgb8
 
     def render_sums(self, params, begin, count):
@@ -146,6 +156,21 @@ def test_tiled_continue_resumes_from_the_file(tmp_path):
     want, _ = O.render(second, second.params, want)
     assert np.array_equal(got, want)
     assert passes(second.params) == (2, 1, True, 2)
+
+
+@pytest.mark.parametrize("incremental", [None, 2])
+def test_tile_loop_with_a_pool_of_backend_buffers(tmp_path, incremental):
+    """A backend that offers pixel buffers (page-locked ones on a GPU): the loop keeps at most three
+    going round, tiles of different sizes share them, and the image is the same."""
+    from oracle import binding as O
+    scene = _scene(4, incremental=incremental)
+    want, _ = O.render(scene, scene.params)
+    backend = OracleTileBackend(scene, pooled=True)
+    with Image(str(tmp_path / "p.ppm"), 40, 28) as img:
+        render_tiled(backend, img, scene.params, 16, 12)  # 3 x 3 tiles, the last column and row smaller
+        assert np.array_equal(img.pixels(), want)
+    passes_run = 2 if incremental else 1
+    assert 1 <= len(backend.made) <= 3 * passes_run and all(b.shape == (12, 16, 3) for b in backend.made)
 
 
 def _worker(rank, world, port, group_size, path, exact=False):
