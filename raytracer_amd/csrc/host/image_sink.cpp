@@ -14,6 +14,8 @@
 #include <cerrno>
 #include <cstdio>
 #include <cstring>
+#include <thread>
+#include <vector>
 #include <new>
 #include <string>
 
@@ -28,6 +30,29 @@ struct RthImage {
 
 static void set_err(char* err, size_t err_len, const std::string& msg) {
     if (err && err_len) std::snprintf(err, err_len, "%s", msg.c_str());
+}
+
+// Rows [0, h) of a tile copied by `copy_row`; tiles of tens of megabytes and more are split over a
+// few threads (one thread moves about 5-10 GB/s through the page cache, a 16384 x 16384 tile is 805 MB).
+template <class CopyRow>
+static void copy_rows(uint32_t h, size_t row_bytes, CopyRow copy_row) {
+    const size_t total = static_cast<size_t>(h) * row_bytes;
+    unsigned n = total >= (size_t{32} << 20) ? 4u : 1u;
+    std::vector<std::thread> workers;
+    try {
+        for (unsigned t = 1; t < n; ++t)
+            workers.emplace_back([=] {
+                for (uint32_t r = static_cast<uint32_t>(static_cast<uint64_t>(h) * t / n); r < static_cast<uint64_t>(h) * (t + 1) / n; ++r) copy_row(r);
+            });
+    } catch (...) {
+        n = static_cast<unsigned>(workers.size()) + 1;  // threads could not be had: this one does what is left
+        for (std::thread& w : workers) w.join();
+        workers.clear();
+        for (uint32_t r = 0; r < h; ++r) copy_row(r);  // (copies are idempotent)
+        return;
+    }
+    for (uint32_t r = 0; r < static_cast<uint64_t>(h) / n; ++r) copy_row(r);
+    for (std::thread& w : workers) w.join();
 }
 
 extern "C" {
@@ -86,18 +111,16 @@ static bool tile_inside(const RthImage* image, uint32_t x, uint32_t y, uint32_t 
 int rth_image_read_tile(const RthImage* image, uint32_t x, uint32_t y, uint32_t w, uint32_t h, uint8_t* tile) {
     if (!tile || !tile_inside(image, x, y, w, h)) return -1;
     const uint8_t* px = image->base + image->header_len;
-    const size_t row = static_cast<size_t>(w) * 3;
-    for (uint32_t r = 0; r < h; ++r)
-        std::memcpy(tile + r * row, px + (static_cast<size_t>(y + r) * image->width + x) * 3, row);
+    const size_t row = static_cast<size_t>(w) * 3, width = image->width;
+    copy_rows(h, row, [=](uint32_t r) { std::memcpy(tile + r * row, px + (static_cast<size_t>(y + r) * width + x) * 3, row); });
     return 0;
 }
 
 int rth_image_write_tile(RthImage* image, uint32_t x, uint32_t y, uint32_t w, uint32_t h, const uint8_t* tile) {
     if (!tile || !tile_inside(image, x, y, w, h)) return -1;
     uint8_t* px = image->base + image->header_len;
-    const size_t row = static_cast<size_t>(w) * 3;
-    for (uint32_t r = 0; r < h; ++r)
-        std::memcpy(px + (static_cast<size_t>(y + r) * image->width + x) * 3, tile + r * row, row);
+    const size_t row = static_cast<size_t>(w) * 3, width = image->width;
+    copy_rows(h, row, [=](uint32_t r) { std::memcpy(px + (static_cast<size_t>(y + r) * width + x) * 3, tile + r * row, row); });
     return 0;
 }
 

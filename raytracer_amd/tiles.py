@@ -130,7 +130,10 @@ class TileBackend(Protocol):
     def fold(self, params, carry_on: bool):
         """(exact groups only) Fold the traced samples onto the sums tensor (or start it); returns it."""
 
-    def resolve(self, params, sums, n_samples: int, running: bool, k: int, old: np.ndarray | None) -> np.ndarray: ...
+    def resolve(self, params, sums, n_samples: int, running: bool, k: int, old: np.ndarray | None,
+                out: np.ndarray | None = None) -> np.ndarray:
+        """Mean, gamma, running average with `old` (when running) and quantisation of the tile's sums;
+        the bytes are written over `old`, or into `out` when given (a buffer of the tile loop's pool)."""
 
 
 def pass_params(params, rect, chunk: int, running: bool, k: int):
@@ -189,6 +192,19 @@ def render_tiled(backend: TileBackend, image: Image, params, tile_w: int, tile_h
     image.flush()
 
 
+def _pool_of(backend) -> "_BufferPool":
+    """The backend's pool of pixel buffers, kept on it from one render to the next (page-locked
+    memory is dear to allocate and is not given back until the backend goes)."""
+    pool = getattr(backend, "tile_pool", None)
+    if pool is None:
+        pool = _BufferPool(backend, 3)
+        try:
+            backend.tile_pool = pool
+        except AttributeError:
+            pass
+    return pool
+
+
 class _BufferPool:
     """Up to `n` pixel buffers of the backend's kind (see TileBackend), re-used from tile to
     tile; a tile smaller than a buffer gets a view of its start.  Without `pixel_buffer` on
@@ -237,7 +253,7 @@ def _render_passes(backend, image, params, grid, mine, copier, chunk, n_passes, 
         k = p + first_pass
         if group_size == 1:
             rects = [grid[ti] for ti in mine]
-            pool = _BufferPool(backend, 3)
+            pool = _pool_of(backend)
 
             def read(rect):
                 return image.read_tile(*rect, out=pool.take(rect[3], rect[2]))
@@ -246,14 +262,23 @@ def _render_passes(backend, image, params, grid, mine, copier, chunk, n_passes, 
                 image.write_tile(rect[0], rect[1], tile)
                 pool.give_back(tile)
 
+            # Per tile: the radiance sums are rendered while the helper thread writes the previous
+            # tile back and reads this tile's old bytes (a tile's read is queued behind every earlier
+            # write, so a pass of one single tile reads what the pass before stored); then mean,
+            # gamma, running average and quantisation on those bytes (rt_render's own sequence, taken
+            # in two calls so that the file traffic hides behind the rendering).
             ahead = copier.submit(read, rects[0]) if running and rects else None
             writing = None
             for n, rect in enumerate(rects):
+                tp = pass_params(params, rect, chunk, running, k)
+                if running and k * chunk + chunk > 0xFFFFFFFF:
+                    raise ValueError("sample index overflow")
+                sums = backend.render_sums(tp, k * chunk if running else 0, chunk)
                 if writing is not None:  # (before the next read is queued: the pool's third buffer comes back with it)
                     writing.result()
                 old = ahead.result() if ahead is not None else pool.take(rect[3], rect[2])
                 ahead = copier.submit(read, rects[n + 1]) if running and n + 1 < len(rects) else None
-                new = backend.render_tile_pass(pass_params(params, rect, chunk, running, k), old if running else None, out=old)
+                new = backend.resolve(tp, sums, chunk, running, k, old if running else None, out=old)
                 writing = copier.submit(write, rect, new)
             if writing is not None:
                 writing.result()
@@ -377,8 +402,11 @@ class GpuTileBackend:
         self.renderer.fold_samples(params, carry_on, t.data_ptr(), sums_on_device=True)
         return t
 
-    def resolve(self, params, sums, n_samples, running, k, old):
+    def resolve(self, params, sums, n_samples, running, k, old, out=None):
         h, w = params.tile_shape()
-        rgb8 = np.zeros((h, w, 3), dtype=np.uint8) if old is None else np.ascontiguousarray(old)
+        if old is not None:
+            rgb8 = np.ascontiguousarray(old)
+        else:
+            rgb8 = out if out is not None else np.zeros((h, w, 3), dtype=np.uint8)
         return self.renderer.resolve(params, sums.data_ptr(), n_samples, running_average=running, sample_iteration=k,
                                      rgb8=rgb8, sums_on_device=True)

@@ -87,11 +87,15 @@ class OracleTileBackend:
         h, w = params.tile_shape()
         return torch.zeros(h * w * 3, dtype=torch.float32)
 
-    def resolve(self, params, sums, n_samples, running, k, old):
+    def resolve(self, params, sums, n_samples, running, k, old, out=None):
         from oracle import binding as O
         h, w = params.tile_shape()
-        return O.resolve(params, sums.numpy().reshape(h, w, 3), n_samples, running, k,
+        rgb8 = O.resolve(params, sums.numpy().reshape(h, w, 3), n_samples, running, k,
                          None if old is None else np.ascontiguousarray(old))
+        if out is not None:
+            out[...] = rgb8
+            return out
+        return rgb8
 
     # the exact hand-over inside a group: per-sample radiance kept until the fold
     def sums(self, params):
