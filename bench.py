@@ -49,7 +49,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, spec
 
 
 VALU_PEAK_GINSTR = 1024 * 2.4 / 2.0  # 1024 SIMDs x 2.4 GHz, one wave64 vector instruction per 2 cycles: 1228.8 G/s
-PROFILE = os.path.join(ROOT, "profiles", "r02_counters.json")
+PROFILE = os.path.join(ROOT, "profiles", "r03_counters.json")
 
 
 def _code_only(text: str) -> str:

@@ -342,6 +342,7 @@ struct TraceArgs {
     uint32_t pair_min;       // SHARE: pending (ray, triangle) pairs that trigger a shared shape step
     uint32_t cache_nodes;    // branch records [0, cache_nodes) are copied to LDS by each workgroup
     uint32_t refill_min;     // idle lanes that trigger a refill from the queue (1..64)
+    uint32_t guided;         // 1: reservations shrink towards the end of the queue (see trace_loop)
     int bounds_fast;         // every box coordinate is 0 or has magnitude in [2^-60, 2^59)
     unsigned long long* counters;  // [0] branch visits, [1] shape tests (COUNT only)
     unsigned long long* wave_tallies;  // six diagnostic words, triangle family only (COUNT only)
@@ -378,7 +379,7 @@ template <int KIND, bool COUNT, bool SHARE, int WAVES, bool FASTSLAB>
 __device__ __forceinline__ void trace_loop(const TraceArgs& a, const DQueue& q, const float4* s_nodes, uint2* s_stack,
                                            unsigned long long* s_res, uint32_t* s_mark, uint32_t lane, uint32_t gtid,
                                            uint32_t cache_nodes, uint32_t n, uint32_t chunk, uint32_t pool_first,
-                                           uint32_t pool_last, bool no_more) {
+                                           uint32_t pool_last, bool no_more, uint32_t tail_shift = 31u) {
     const int lds_slots = static_cast<int>(a.lds_slots);
     const DNode* __restrict__ nodes = a.fam.nodes;
 
@@ -404,6 +405,7 @@ __device__ __forceinline__ void trace_loop(const TraceArgs& a, const DQueue& q, 
 
     bool active = false, exhausted = no_more, fast = false;
     uint32_t pool_next = pool_first, pool_end = pool_last;  // wave-uniform: rays reserved for this wave
+    uint32_t reserve = chunk;  // size of this wave's next reservation
     uint32_t ray = 0, best_i = kHitNone;
     int sp = 0;
     F3 o = f3(0, 0, 0), d = f3(0, 0, 0);
@@ -447,11 +449,15 @@ __device__ __forceinline__ void trace_loop(const TraceArgs& a, const DQueue& q, 
                 if (pool_next == pool_end) {
                     // reserve the next block of the queue for this wave
                     uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(a.cursor, chunk);
+                    if (lane == 0) base = atomicAdd(a.cursor, reserve);
                     base = __builtin_amdgcn_readfirstlane(base);
                     pool_next = min(base, n);
-                    pool_end = min(base + chunk, n);
-                    if (base + chunk >= n) exhausted = true;
+                    pool_end = min(base + reserve, n);
+                    if (base + reserve >= n) exhausted = true;
+                    // Reservations shrink as the queue runs out (down to one wave's worth), so that
+                    // the launch's waves finish at about the same time instead of each working off a
+                    // full last block alone: what is left, shared among all waves, halved.
+                    if (a.guided) reserve = min(chunk, max(64u, ((n - pool_end) >> tail_shift) & ~63u));
                 }
                 const uint32_t take = min(n_idle, pool_end - pool_next);
                 const uint32_t rank = bits_below_lane(idle);
@@ -722,7 +728,10 @@ __global__ void __launch_bounds__(kTraceBlock * WAVES) __attribute__((amdgpu_num
     // Reservation size: large for long queues (few atomics), one wave's worth for
     // short ones so that the rays still spread over all waves of the grid.
     const uint32_t chunk = min(a.chunk_max, max(64u, (n / (2u * gridDim.x * WAVES)) & ~63u));
-    trace_loop<KIND, COUNT, SHARE, WAVES, FASTSLAB>(a, a.q, s_nodes, s_stack, s_res, s_mark, lane, gtid, cache_nodes, n, chunk, 0u, 0u, false);
+    // log2 of twice the number of waves, rounded up: "what is left / (2 x waves)" as a shift
+    const uint32_t tail_shift = 32u - static_cast<uint32_t>(__builtin_clz(2u * gridDim.x * WAVES - 1u));
+    trace_loop<KIND, COUNT, SHARE, WAVES, FASTSLAB>(a, a.q, s_nodes, s_stack, s_res, s_mark, lane, gtid, cache_nodes, n, chunk, 0u, 0u, false,
+                                                    tail_shift);
 }
 
 // --------------------------------------------------- inlined small families

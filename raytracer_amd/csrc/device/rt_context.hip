@@ -123,6 +123,7 @@ struct RtContext {
     uint32_t max_grid_threads = 0; // upper bound of the traversal grid's threads (sizes the spill area)
     uint32_t tune_lds_slots = 6, tune_phase_min = 24, tune_chunk_max = 256, tune_pair_min = 384;
     uint32_t tune_waves_per_cu = 0; // traversal waves resident per CU (0 = all the kernel's occupancy allows)
+    bool tune_guided = true;        // queue reservations shrink towards the end of a launch
     uint32_t tune_refill_min = 12;  // idle lanes that trigger a refill
     uint32_t tune_waves = 8;        // waves per traversal workgroup (1, 8 or 16)
     uint32_t tune_cache_nodes = 144;  // branch records each multi-wave workgroup copies to LDS
@@ -532,6 +533,7 @@ int launch_trace(RtContext* ctx, const DQueue& q, const uint32_t* n_rays, uint32
         a.chunk_max = ctx->tune_chunk_max;
         a.pair_min = ctx->tune_pair_min;
         a.refill_min = ctx->tune_refill_min;
+        a.guided = ctx->tune_guided ? 1u : 0u;
         a.bounds_fast = ctx->fam[kind].bounds_fast ? 1 : 0;
         a.counters = ctx->d_stats + 1 + 2 * kind;  // [branch visits, shape tests] of this family
         a.wave_tallies = kind == RT_SHAPE_TRIANGLE ? ctx->d_stats + 9 : nullptr;
@@ -1158,6 +1160,7 @@ int rt_set_option(RtContext* ctx, uint32_t option, uint64_t value) try {
             if (value < 64 || value > (1u << 24) || value % 64) return fail(ctx, RT_ERR_INVALID, "path group must be a multiple of 64 in 64..2^24");
             ctx->tune_path_group = static_cast<uint32_t>(value);
             return RT_OK;
+        case RT_OPT_TRACE_GUIDED: ctx->tune_guided = value != 0; return RT_OK;
         case RT_OPT_DEBUG_THROW:
             // test hook of the boundary's exception guard: the exception leaves through this very function
             if (value == 1) throw std::bad_alloc();

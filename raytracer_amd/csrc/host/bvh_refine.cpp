@@ -12,8 +12,10 @@
 // reference's tree still covers the same set; `order` records where each came from.
 //
 // What changes and what does not: ray/box and ray/triangle arithmetic are untouched, so a
-// ray's nearest hit DISTANCE is the same number.  Which of several triangles at exactly
-// that distance is reported can differ (the reference keeps the lowest index inside a
+// ray's nearest hit DISTANCE is the same number unless the ray grazes the box of one of the
+// new, smaller leaves (the slab test is not conservative: a hit on the very edge of a
+// triangle can lie in a box the ray numerically misses).  Which of several triangles at
+// exactly that distance is reported can differ (the reference keeps the lowest index inside a
 // leaf and the first leaf visited; both depend on the tree), and primitive ids are
 // positions after this permutation: map them back through `order` to compare.
 #include <algorithm>

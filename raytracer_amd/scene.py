@@ -124,7 +124,8 @@ class Scene:
         the reference's triangle tree with every leaf above `max_leaf` triangles split on,
         past the stop rule of /root/reference/src/bvh.rs:169.  Returns (scene, order):
         triangle i of the new scene is triangle order[i] of this one.  Hit distances are the
-        same numbers; primitive ids are positions in the new order."""
+        same numbers (but for rays that graze a new leaf's box); primitive ids are positions in
+        the new order."""
         lib = F.host_lib()
         tris = self.triangles.copy()
         order = np.zeros(tris.size, dtype=np.uint32)

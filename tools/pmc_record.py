@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turn the counter passes of tools/pmc_profile.sh into the record bench.py reads
-(profiles/r02_counters.json): per workload, the traversal and shading kernels'
+(profiles/r03_counters.json): per workload, the traversal and shading kernels'
 hardware counters per launch and per ray, stamped with a hash of the kernel sources
 they were measured on, so that a record of other kernels is never quoted.
 
@@ -62,6 +62,22 @@ def kernel_record(t, c, rays):
         out["valu_cycles_per_inst"] = round(4.0 * t["SQ_ACTIVE_INST_VALU"] / t["SQ_INSTS_VALU"], 3)
     if t.get("SQ_WAVE_CYCLES") and simd_cycles:
         out["waves_per_simd"] = round(4.0 * t["SQ_WAVE_CYCLES"] / simd_cycles, 2)
+    # where a wave's time goes (quad-cycle counters; shares of the waves' resident time)
+    if t.get("SQ_WAVE_CYCLES"):
+        wc = t["SQ_WAVE_CYCLES"]
+        for name, key in (("SQ_WAIT_ANY", "wait_any_share"), ("SQ_WAIT_INST_ANY", "wait_inst_any_share"),
+                          ("SQ_WAIT_INST_LDS", "wait_inst_lds_share"), ("SQ_ACTIVE_INST_ANY", "active_inst_any_share"),
+                          ("SQ_ACTIVE_INST_VALU", "active_inst_valu_share"), ("SQ_ACTIVE_INST_LDS", "active_inst_lds_share"),
+                          ("SQ_ACTIVE_INST_VMEM", "active_inst_vmem_share"), ("SQ_ACTIVE_INST_SCA", "active_inst_scalar_share")):
+            if t.get(name) is not None:
+                out[key] = round(t[name] / wc, 4)
+    # average time an instruction of the kind is in flight (issue to return), in cycles
+    if t.get("SQ_INST_LEVEL_VMEM") and t.get("SQ_INSTS_VMEM"):
+        out["vmem_latency_cycles"] = round(t["SQ_INST_LEVEL_VMEM"] / t["SQ_INSTS_VMEM"], 1)
+    if t.get("SQ_INST_LEVEL_LDS") and t.get("SQ_INSTS_LDS"):
+        out["lds_latency_cycles"] = round(t["SQ_INST_LEVEL_LDS"] / t["SQ_INSTS_LDS"], 1)
+    if t.get("TCP_PENDING_STALL_CYCLES_sum") is not None and t.get("GRBM_GUI_ACTIVE"):
+        out["tcp_pending_stall_share_of_cu_cycles"] = round(t["TCP_PENDING_STALL_CYCLES_sum"] / (t["GRBM_GUI_ACTIVE"] * 32.0), 4)
     if t.get("SQ_LDS_IDX_ACTIVE"):
         # SQ_LDS_BANK_CONFLICT = LDS-array cycles added by conflicts, SQ_LDS_IDX_ACTIVE = all LDS-array cycles
         out["lds_bank_conflict_share"] = round(t["SQ_LDS_BANK_CONFLICT"] / t["SQ_LDS_IDX_ACTIVE"], 4)
@@ -100,6 +116,8 @@ def main():
     shade = next(k for k in tot if "k_shade" in k)
     args = line["bench_args"]
     key = f"{args['workload']}:{args['width']}x{args['height']}:b{args['bounces']}:d{args['detail']}:fast{int(fast)}"
+    if args.get("fast_build"):
+        key += f":leaf{args['fast_build']}"
     try:
         with open(out_path) as f:
             rec = json.load(f)
