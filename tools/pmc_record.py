@@ -71,11 +71,6 @@ def kernel_record(t, c, rays):
                           ("SQ_ACTIVE_INST_VMEM", "active_inst_vmem_share"), ("SQ_ACTIVE_INST_SCA", "active_inst_scalar_share")):
             if t.get(name) is not None:
                 out[key] = round(t[name] / wc, 4)
-    # average time an instruction of the kind is in flight (issue to return), in cycles
-    if t.get("SQ_INST_LEVEL_VMEM") and t.get("SQ_INSTS_VMEM"):
-        out["vmem_latency_cycles"] = round(t["SQ_INST_LEVEL_VMEM"] / t["SQ_INSTS_VMEM"], 1)
-    if t.get("SQ_INST_LEVEL_LDS") and t.get("SQ_INSTS_LDS"):
-        out["lds_latency_cycles"] = round(t["SQ_INST_LEVEL_LDS"] / t["SQ_INSTS_LDS"], 1)
     if t.get("TCP_PENDING_STALL_CYCLES_sum") is not None and t.get("GRBM_GUI_ACTIVE"):
         out["tcp_pending_stall_share_of_cu_cycles"] = round(t["TCP_PENDING_STALL_CYCLES_sum"] / (t["GRBM_GUI_ACTIVE"] * 32.0), 4)
     if t.get("SQ_LDS_IDX_ACTIVE"):
