@@ -165,10 +165,13 @@ __device__ __forceinline__ bool triangle_hit(v2f ex, v2f ey, v2f ez, F3 a, F3 o,
     const bool ok_v = !(v < 0.0f || u + v > 1.0f);
     return ok_det & ok_u & ok_v & (t > kMinDistance);
 }
-__device__ __forceinline__ bool triangle_hit(const DTriangle* tri, F3 o, F3 d, float& t) {
-    const float4* tp = reinterpret_cast<const float4*>(tri);
-    const float4 v0 = tp[0], v1 = tp[1];
-    const float az = tri->a[2];
+// Triangle `i` of a family's three triangle arrays (layout.h).
+__device__ __forceinline__ bool triangle_hit(const DFamily& fam, uint32_t i, F3 o, F3 d, float& t) {
+    const float4* p0 = static_cast<const float4*>(fam.shapes);
+    const float4* p1 = p0 + fam.n_shapes;
+    const float* pz = reinterpret_cast<const float*>(p1 + fam.n_shapes);
+    const float4 v0 = p0[i], v1 = p1[i];
+    const float az = pz[i];
     return triangle_hit(v2f{v0.x, v0.y}, v2f{v0.z, v0.w}, v2f{v1.x, v1.y}, f3(v1.z, v1.w, az), o, d, t);
 }
 
@@ -651,7 +654,7 @@ __device__ __forceinline__ void trace_loop(const TraceArgs& a, const DQueue& q, 
                     }
                     if (j < N && tri < a.fam.n_shapes) {  // the second test only keeps a logic error from reading outside the table
                         float t;
-                        if (triangle_hit(static_cast<const DTriangle*>(a.fam.shapes) + tri, oo, dd, t))
+                        if (triangle_hit(a.fam, tri, oo, dd, t))
                             atomicMin(&s_res[owner], (static_cast<unsigned long long>(__float_as_uint(t)) << 32) | tri);
                     }
                 }
@@ -683,7 +686,7 @@ __device__ __forceinline__ void trace_loop(const TraceArgs& a, const DQueue& q, 
                 } else if (KIND == 1) {
                     hit = plane_hit(static_cast<const DPlane*>(a.fam.shapes)[i], o, d, t);
                 } else {
-                    hit = triangle_hit(static_cast<const DTriangle*>(a.fam.shapes) + i, o, d, t);
+                    hit = triangle_hit(a.fam, i, o, d, t);
                 }
                 if (hit && t < best_t) {
                     best_t = t;

@@ -13,8 +13,9 @@
 //                    first shape index, or count field 15 = "long leaf" with
 //                    bits 0..26 indexing a {first, count} table
 //     so a traversal stack entry is 8 bytes: entry distance + reference.
-//   * triangles: 48 bytes each (three 16-byte loads): a, e1, e2 and one
-//     padding dword — the operands of /root/reference/src/shapes.rs:232-259.
+//   * triangles: 36 bytes each in three arrays (two 16-byte loads and one
+//     4-byte load, consecutive triangles consecutive in each): a, e1, e2 — the
+//     operands of /root/reference/src/shapes.rs:232-259.
 //     Shading attributes live in separate arrays, untouched by traversal.
 //
 // Path queues (one record per live path, structure-of-arrays so that a wave
@@ -47,17 +48,18 @@ struct alignas(16) DNode {
 };
 static_assert(sizeof(DNode) == 64, "branch record must be one 64-byte line");
 
-struct alignas(16) DTriangle {
-    // per axis: (e2, e1) side by side — the two cross products of the
-    // intersection test, d x e2 and (o - a) x e1, run as the two halves of the
-    // packed (two-wide) arithmetic, so each loaded register pair is one operand
-    float ex[2];
-    float ey[2];
-    float ez[2];
-    float a[3];
-    float pad[3];
+// The triangles of the traversal: 36 bytes each, as three arrays one after the other in one
+// allocation of n triangles — n x {ex[2], ey[2]}, n x {ez[2], a.x, a.y}, n x a.z — where
+// ex/ey/ez hold (e2, e1) of one axis side by side: the two cross products of the intersection
+// test, d x e2 and (o - a) x e1, run as the two halves of the packed (two-wide) arithmetic, so
+// each loaded register pair is one operand.  Arrays rather than one record per triangle because
+// the lanes of a shared triangle step read runs of consecutive triangles (a leaf's): a load
+// instruction then touches a third of the memory lines it would touch in 48-byte records, and
+// the level-one cache's work goes by the line.
+struct alignas(16) DTriHalf {
+    float v[4];
 };
-static_assert(sizeof(DTriangle) == 48, "triangle record is three 16-byte loads");
+__host__ __device__ inline size_t triangle_array_bytes(size_t n) { return n * (2 * sizeof(DTriHalf) + sizeof(float)); }
 
 struct alignas(16) DSphere {
     float center[3];
@@ -115,7 +117,7 @@ struct DMaterial {
 struct DFamily {
     const DNode* nodes;
     const DLongLeaf* long_leaves;
-    const void* shapes;  // DSphere / DPlane / DTriangle
+    const void* shapes;  // DSphere / DPlane / the three triangle arrays (DTriHalf x n, DTriHalf x n, float x n)
     uint32_t root_ref;
     uint32_t n_shapes;
     uint32_t max_stack;  // deepest stack the traversal can need (tree depth + 1)

@@ -1261,15 +1261,18 @@ int rt_upload_scene(RtContext* ctx, const RtSceneDesc* s) try {
             pl[i].pad0 = pl[i].pad1 = 0.0f;
             pm[i] = s->planes[i].material;
         }
-        std::vector<DTriangle> tr(s->n_triangles);
+        // the traversal's three triangle arrays, one after the other (layout.h)
+        const size_t nt = s->n_triangles;
+        std::vector<unsigned char> tr(triangle_array_bytes(nt));
+        DTriHalf* const tr0 = reinterpret_cast<DTriHalf*>(tr.data());
+        DTriHalf* const tr1 = tr0 + nt;
+        float* const trz = reinterpret_cast<float*>(tr1 + nt);
         std::vector<DTriSurface> ts(s->n_triangles);
         for (uint32_t i = 0; i < s->n_triangles; ++i) {
             const RtTriangle& t = s->triangles[i];
-            std::memcpy(tr[i].a, t.a, 12);
-            tr[i].ex[0] = t.e2[0]; tr[i].ex[1] = t.e1[0];
-            tr[i].ey[0] = t.e2[1]; tr[i].ey[1] = t.e1[1];
-            tr[i].ez[0] = t.e2[2]; tr[i].ez[1] = t.e1[2];
-            tr[i].pad[0] = tr[i].pad[1] = tr[i].pad[2] = 0.0f;
+            tr0[i] = DTriHalf{{t.e2[0], t.e1[0], t.e2[1], t.e1[1]}};  // ex, ey
+            tr1[i] = DTriHalf{{t.e2[2], t.e1[2], t.a[0], t.a[1]}};    // ez, a.x, a.y
+            trz[i] = t.a[2];
             DTriSurface& d = ts[i];
             std::memset(&d, 0, sizeof d);
             std::memcpy(d.a, t.a, 12);
@@ -1330,7 +1333,7 @@ int rt_upload_scene(RtContext* ctx, const RtSceneDesc* s) try {
         }
         DSphere* dsp = nullptr;
         DPlane* dpl = nullptr;
-        DTriangle* dtr = nullptr;
+        unsigned char* dtr = nullptr;
         int rc = upload(ctx, &dsp, sp.data(), sp.size());
         ctx->fam[0].shapes = dsp;
         if (!rc) { rc = upload(ctx, &dpl, pl.data(), pl.size()); ctx->fam[1].shapes = dpl; }
