@@ -100,6 +100,12 @@ def test_command_line_renderer_tiles_large_frames(asset_root, tmp_path):
     scene = scenes.room(asset_root, w=80, h=50, spp=4, bounces=8, incremental=2)
     cpu, _ = O.render(scene, scene.params, threads=4)
     assert a[len(b"P6\n80 50 255\n"):] == cpu.tobytes()
+    # the opt-in refined tree (RT_RENDER_MAX_LEAF): the oracle on the same refined scene stores the same bytes
+    out_d = str(tmp_path / "d.ppm")
+    subprocess.run([exe, str(scene_file), out_d, "0"], cwd=asset_root, check=True, env=dict(env, RT_RENDER_MAX_LEAF="4"), timeout=120)
+    refined, _ = scene.refined(4)
+    cpu_refined, _ = O.render(refined, refined.params, threads=4)
+    assert open(out_d, "rb").read()[len(b"P6\n80 50 255\n"):] == cpu_refined.tobytes()
 
 
 def _hybrid_worker(rank, world, port, group_size, path, asset_root, exact=False):
