@@ -167,11 +167,14 @@ __device__ __forceinline__ bool triangle_hit(v2f ex, v2f ey, v2f ez, F3 a, F3 o,
 }
 // Triangle `i` of a family's three triangle arrays (layout.h).
 __device__ __forceinline__ bool triangle_hit(const DFamily& fam, uint32_t i, F3 o, F3 d, float& t) {
-    const float4* p0 = static_cast<const float4*>(fam.shapes);
-    const float4* p1 = p0 + fam.n_shapes;
-    const float* pz = reinterpret_cast<const float*>(p1 + fam.n_shapes);
-    const float4 v0 = p0[i], v1 = p1[i];
-    const float az = pz[i];
+    // (32-bit byte offsets from wave-uniform bases — a family holds fewer than 2^27 shapes — so that
+    // the loads take their base from scalar registers and no 64-bit address is computed per lane)
+    const char* b0 = static_cast<const char*>(fam.shapes);
+    const char* b1 = b0 + static_cast<size_t>(fam.n_shapes) * sizeof(DTriHalf);
+    const char* bz = b1 + static_cast<size_t>(fam.n_shapes) * sizeof(DTriHalf);
+    const uint32_t o16 = i << 4, o4 = i << 2;
+    const float4 v0 = *reinterpret_cast<const float4*>(b0 + o16), v1 = *reinterpret_cast<const float4*>(b1 + o16);
+    const float az = *reinterpret_cast<const float*>(bz + o4);
     return triangle_hit(v2f{v0.x, v0.y}, v2f{v0.z, v0.w}, v2f{v1.x, v1.y}, f3(v1.z, v1.w, az), o, d, t);
 }
 
