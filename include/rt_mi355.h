@@ -242,6 +242,7 @@ typedef enum RtOption {
      * where it is the faster loop (several times faster for previews and single-sample passes).
      * Results do not depend on it. */
     RT_OPT_FUSED_LOOP = 17,
+    RT_OPT_PASSES_IN_FLIGHT = 21, /* rt_render: passes (of `incremental` samples) whose paths are traced together before the passes are finished one by one, in order — same bytes; the image is rewritten once per such group. 0 (default) = as many as make 2^26 paths, 1 = one pass at a time */
     RT_OPT_TRACE_GUIDED = 20, /* 0/1 (default 1): a wave's reservations from the ray queue shrink as the queue runs out, so that a launch's waves finish together */
     RT_OPT_DEBUG_THROW = 19, /* test hook: 1 makes this very rt_set_option call fail inside with std::bad_alloc, 2 with another
                               * exception; the call must come back with RT_ERR_OOM / RT_ERR_HIP (nothing throws across the boundary) */

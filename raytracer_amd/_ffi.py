@@ -27,7 +27,7 @@ RT_OPT_TRACE_LDS_SLOTS, RT_OPT_TRACE_PHASE_MIN, RT_OPT_TRACE_CHUNK = 4, 5, 6
 RT_OPT_TRACE_SHARE, RT_OPT_TRACE_PAIR_MIN = 7, 8
 RT_OPT_TRACE_WAVES, RT_OPT_TRACE_CACHE_NODES, RT_OPT_TRACE_REFILL_MIN = 9, 10, 11
 RT_OPT_TRACE_WAVES_PER_CU, RT_OPT_CHAINS, RT_OPT_SHADE_GROUPS_PER_CU, RT_OPT_FAST_SLAB = 12, 13, 14, 15
-RT_OPT_FUSED_LOOP, RT_OPT_PATH_GROUP, RT_OPT_DEBUG_THROW, RT_OPT_TRACE_GUIDED = 17, 18, 19, 20
+RT_OPT_FUSED_LOOP, RT_OPT_PATH_GROUP, RT_OPT_DEBUG_THROW, RT_OPT_TRACE_GUIDED, RT_OPT_PASSES_IN_FLIGHT = 17, 18, 19, 20, 21
 
 f32, u32, u64, u8 = C.c_float, C.c_uint32, C.c_uint64, C.c_uint8
 

@@ -133,6 +133,7 @@ struct RtContext {
     uint32_t opt_fused = 2;  // the whole bounce loop in one launch (k_path): 0 never, 1 whenever the scene allows, 2 for batches below kFusedBelowPaths
     bool debug_tallies = std::getenv("RT_MI355_DEBUG_TALLIES") != nullptr;  // slow diagnostics of the counting kernels
     uint64_t opt_samples_in_flight = 0;  // 0 = automatic
+    uint64_t opt_passes_in_flight = 0;   // rt_render: passes traced together (0 = automatic, 1 = one at a time)
     std::vector<hipEvent_t> events;      // pairs around timed launches
     size_t events_used = 0;
 
@@ -1161,6 +1162,7 @@ int rt_set_option(RtContext* ctx, uint32_t option, uint64_t value) try {
             ctx->tune_path_group = static_cast<uint32_t>(value);
             return RT_OK;
         case RT_OPT_TRACE_GUIDED: ctx->tune_guided = value != 0; return RT_OK;
+        case RT_OPT_PASSES_IN_FLIGHT: ctx->opt_passes_in_flight = value; return RT_OK;
         case RT_OPT_DEBUG_THROW:
             // test hook of the boundary's exception guard: the exception leaves through this very function
             if (value == 1) throw std::bad_alloc();
@@ -1514,18 +1516,55 @@ int rt_render(RtContext* ctx, const RtRenderParams* p, uint8_t* rgb8, RtProgress
     rc = ensure_workspace(ctx, 0, r.n_pixels, 0);
     if (rc) return rc;
     if (running) HIP_TRY(ctx, hipMemcpyAsync(ctx->ws.rgb8, rgb8, r.n_pixels * 3, hipMemcpyHostToDevice, ctx->stream));
-    for (uint32_t pass = 0; pass < n_passes; ++pass) {
+    // Passes of few samples (the reference's shipped scenes use `incremental(1)`) are short batches of paths,
+    // which render at a fraction of the rate of long ones.  What a pass depends on in the pass before it is
+    // only the stored bytes it blends into (lib.rs:286-292), not its paths: the paths of several passes are
+    // therefore traced together, and the passes are then finished one after the other from the per-sample
+    // radiance — fold of the pass's samples, mean, gamma, running average, quantisation — in pass order, which
+    // is the same arithmetic on the same values as pass by pass.  The image is rewritten after each such group of
+    // passes (at most 2^26 paths, a fraction of a second) and progress is reported for each of its passes.
+    const uint64_t pass_paths = static_cast<uint64_t>(chunk) * r.n_pixels;
+    uint32_t group = 1;
+    if (n_passes > 1 && p->max_bounces > 0 && pass_paths < (uint64_t{1} << 26)) {
+        const uint64_t budget = ctx->opt_passes_in_flight ? ctx->opt_passes_in_flight : (uint64_t{1} << 26) / pass_paths;
+        group = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(budget, n_passes)));
+    }
+    const uint32_t n_pix = static_cast<uint32_t>(r.n_pixels);
+    for (uint32_t pass = 0; pass < n_passes;) {
         const uint32_t k = pass + first_pass;  // sample_iteration, lib.rs:233-234
-        const uint64_t s_begin = static_cast<uint64_t>(k) * chunk;
-        if (s_begin + chunk > 0xFFFFFFFFull) return fail(ctx, RT_ERR_INVALID, "sample index overflow");
-        rc = render_sums_device(ctx, p, r, static_cast<uint32_t>(s_begin), chunk);
-        if (rc) return rc;
-        rc = quantize_device(ctx, ctx->ws.sums, r.n_pixels, chunk, running, k);
-        if (rc) return rc;
-        // the image file is readable after every pass (live preview)
+        uint32_t together = std::min(group, n_passes - pass);
+        if ((static_cast<uint64_t>(k) + together) * chunk > 0xFFFFFFFFull) return fail(ctx, RT_ERR_INVALID, "sample index overflow");
+        if (together > 1) {
+            size_t S = 0;
+            rc = workspace_for_samples(ctx, r, together * chunk, p->max_bounces, &S);
+            if (rc) return rc;
+            together = static_cast<uint32_t>(S / chunk);  // whole passes of what fits in flight
+        }
+        if (together <= 1) {
+            rc = render_sums_device(ctx, p, r, k * chunk, chunk);
+            if (rc) return rc;
+            rc = quantize_device(ctx, ctx->ws.sums, r.n_pixels, chunk, running, k);
+            if (rc) return rc;
+            together = 1;
+        } else {
+            ctx->pending_samples = 0;  // the result array is about to be overwritten
+            rc = trace_batch(ctx, frame_args(p, r), device_scene(ctx), p->max_bounces, n_pix, static_cast<unsigned long long>(k) * chunk,
+                             together * chunk);
+            if (rc) return rc;
+            for (uint32_t j = 0; j < together; ++j) {
+                hipLaunchKernelGGL(k_fold, dim3((n_pix + 255) / 256), dim3(256), 0, ctx->stream,
+                                   ctx->ws.result + static_cast<size_t>(j) * chunk * n_pix, ctx->ws.sums, n_pix, chunk, 1);
+                HIP_TRY(ctx, hipGetLastError());
+                rc = quantize_device(ctx, ctx->ws.sums, r.n_pixels, chunk, running, k + j);
+                if (rc) return rc;
+            }
+        }
+        // the image file is readable after every group of passes (live preview)
         HIP_TRY(ctx, hipMemcpyAsync(rgb8, ctx->ws.rgb8, r.n_pixels * 3, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if (progress) progress(first_pass + (pass + 1) * chunk, user);  // lib.rs:238-246
+        for (uint32_t j = 0; j < together; ++j)
+            if (progress) progress(first_pass + (pass + j + 1) * chunk, user);  // lib.rs:238-246
+        pass += together;
     }
     ctx->stats.render_ms += timer.ms();
     return RT_OK;

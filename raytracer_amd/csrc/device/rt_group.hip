@@ -270,6 +270,11 @@ int rt_group_render(RtGroup* g, const RtRenderParams* p, uint8_t* rgb8, RtProgre
     int rc = check_group(g, p);
     if (rc != RT_OK) return rc;
     if (!rgb8) return group_fail(g, RT_ERR_INVALID, "null pixel buffer");
+    if (g->member.size() == 1) {
+        // one GPU: the single-GPU call itself (which traces several short passes together)
+        rc = rt_render(g->member[0], p, rgb8, progress, user);
+        return rc == RT_OK ? RT_OK : member_fail(g, 0, rc);
+    }
     // lib.rs:206-211
     const uint32_t chunk = p->incremental ? p->incremental : p->samples_per_pixel;
     if (chunk == 0 || p->samples_per_pixel % chunk != 0)

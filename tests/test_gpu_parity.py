@@ -242,6 +242,33 @@ def test_incremental_and_continue(renderer):
     assert not np.array_equal(gpu2, gpu)
 
 
+@pytest.mark.parametrize("together", [0, 1, 3, 64])
+def test_short_passes_traced_together_store_the_same_bytes(renderer, asset_root, together):
+    """rt_render traces the paths of several short passes in one batch and finishes the passes in order
+    (RT_OPT_PASSES_IN_FLIGHT: automatic, one at a time, three at a time with a remainder, more than there
+    are): the bytes are the oracle's pass-by-pass bytes, progress is reported per pass, and a tile and a
+    resumed render behave the same."""
+    s = scenes.room(asset_root, w=96, h=54, spp=7, bounces=10, incremental=1)
+    renderer.upload(s)
+    cpu, _ = O.render(s, s.params, threads=4)
+    renderer.set_option(F.RT_OPT_PASSES_IN_FLIGHT, together)
+    try:
+        seen = []
+        assert np.array_equal(renderer.render(s.params, progress=seen.append), cpu)
+        assert seen == [1, 2, 3, 4, 5, 6, 7]
+        # resumed: continue(7), four more passes of one sample, from the stored bytes
+        more = scenes.room(asset_root, w=96, h=54, spp=4, bounces=10, incremental=1, cont=7)
+        cpu2, _ = O.render(more, more.params, rgb8=cpu.copy(), threads=4)
+        assert np.array_equal(renderer.render(more.params, rgb8=cpu.copy()), cpu2)
+        # a tile of the frame
+        t = s.params.copy()
+        t.tile_x, t.tile_y, t.tile_w, t.tile_h = 16, 8, 40, 30
+        cpu_t, _ = O.render(s, t, threads=4)
+        assert np.array_equal(renderer.render(t), cpu_t)
+    finally:
+        renderer.set_option(F.RT_OPT_PASSES_IN_FLIGHT, 0)
+
+
 def test_resolve_matches_oracle(renderer):
     s = scenes.sphere_plane(w=32, h=18, spp=4)
     renderer.upload(s)
