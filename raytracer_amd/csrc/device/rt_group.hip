@@ -14,10 +14,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <new>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "abi_guard.h"
@@ -37,6 +39,19 @@ int rt_context_device(RtContext* ctx, hipStream_t* stream);
 namespace {
 
 thread_local char g_group_error[512] = "";
+
+// Worker threads that are joined whichever way their scope is left: a thread that could not be
+// started (std::system_error) must not leave its already running siblings to be destroyed unjoined.
+struct Workers {
+    std::vector<std::thread> threads;
+    template <class... A>
+    void start(A&&... a) { threads.emplace_back(std::forward<A>(a)...); }
+    void join() {
+        for (std::thread& t : threads)
+            if (t.joinable()) t.join();
+    }
+    ~Workers() { join(); }
+};
 
 int group_fail(RtGroup* g, int code, const std::string& msg) {
     g->error = msg;
@@ -115,12 +130,12 @@ int group_sums(RtGroup* g, const RtRenderParams* p, uint32_t begin, uint32_t cou
             rc[k] = RT_OK;
         }
         {
-            std::vector<std::thread> workers;
+            Workers workers;
             for (uint32_t k = 1; k < n; ++k)
                 if (mine[k])
-                    workers.emplace_back([&, k] { rc[k] = rt_trace_samples(g->member[k], p, begin + first[k], mine[k], &traced[k]); });
+                    workers.start([&, k] { rc[k] = rt_trace_samples(g->member[k], p, begin + first[k], mine[k], &traced[k]); });
             rc[0] = rt_trace_samples(g->member[0], p, begin + first[0], mine[0], &traced[0]);  // mine[0] >= 1
-            for (std::thread& t : workers) t.join();
+            workers.join();
         }
         for (uint32_t k = 0; k < n; ++k) {
             if (rc[k] != RT_OK) return member_fail(g, k, rc[k]);
@@ -151,6 +166,59 @@ int group_sums(RtGroup* g, const RtRenderParams* p, uint32_t begin, uint32_t cou
         }
     }
     *holder = last;
+    return RT_OK;
+}
+
+// A render of many short passes over several GPUs: the region's rows are cut into bands (four per member),
+// the passes are taken in groups, and within a group the members pull bands off a shared counter and render
+// the group's passes of a band with one rt_render call each (which traces those passes' paths together) —
+// `continue` semantics, straight into the band's rows of the caller's buffer.  No data moves between GPUs.
+// A band of a pass is a tile of a pass, whose bytes are those of the untiled render; after every group of
+// passes the caller's buffer is a whole image of that many passes, and progress is reported for each of them.
+int group_render_bands(RtGroup* g, const RtRenderParams* p, uint8_t* rgb8, RtProgressFn progress, void* user, uint32_t n_passes,
+                       uint32_t chunk, uint32_t first_pass) {
+    const uint32_t n = static_cast<uint32_t>(g->member.size());
+    const uint32_t x0 = p->tile_w ? p->tile_x : 0u, y0 = p->tile_w ? p->tile_y : 0u;
+    const uint32_t w = p->tile_w ? p->tile_w : p->width, h = p->tile_w ? p->tile_h : p->height;
+    const uint32_t n_bands = std::min(h, 4u * n);
+    // passes per group: a band's call should be a batch of about 2^25 paths
+    const uint64_t band_pass_paths = std::max<uint64_t>(1, static_cast<uint64_t>(chunk) * w * ((h + n_bands - 1) / n_bands));
+    const uint32_t per_group = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(n_passes, (uint64_t{1} << 25) / band_pass_paths)));
+    if ((static_cast<uint64_t>(first_pass) + n_passes) * chunk > 0xFFFFFFFFull) return group_fail(g, RT_ERR_INVALID, "sample index overflow");
+    for (uint32_t pass = 0; pass < n_passes; pass += per_group) {
+        const uint32_t now = std::min(per_group, n_passes - pass);
+        RtRenderParams bp = *p;
+        bp.samples_per_pixel = now * chunk;
+        bp.incremental = chunk;
+        bp.has_continue = 1;
+        bp.continue_sampling = first_pass + pass;
+        bp.tile_x = x0;
+        bp.tile_w = w;
+        std::atomic<uint32_t> next{0};
+        std::vector<int> rc(n, RT_OK);
+        auto work = [&](uint32_t k) {
+            for (;;) {
+                const uint32_t b = next.fetch_add(1);
+                if (b >= n_bands || rc[k] != RT_OK) return;
+                const uint32_t r0 = static_cast<uint32_t>(static_cast<uint64_t>(h) * b / n_bands);
+                const uint32_t r1 = static_cast<uint32_t>(static_cast<uint64_t>(h) * (b + 1) / n_bands);
+                RtRenderParams mine = bp;
+                mine.tile_y = y0 + r0;
+                mine.tile_h = r1 - r0;
+                rc[k] = rt_render(g->member[k], &mine, rgb8 + static_cast<size_t>(r0) * w * 3, nullptr, nullptr);
+            }
+        };
+        {
+            Workers workers;
+            for (uint32_t k = 1; k < n; ++k) workers.start(work, k);
+            work(0);
+            workers.join();
+        }
+        for (uint32_t k = 0; k < n; ++k)
+            if (rc[k] != RT_OK) return member_fail(g, k, rc[k]);
+        for (uint32_t j = 0; j < now; ++j)
+            if (progress) progress(first_pass + (pass + j + 1) * chunk, user);  // lib.rs:238-246
+    }
     return RT_OK;
 }
 
@@ -242,10 +310,10 @@ int rt_group_upload_scene(RtGroup* g, const RtSceneDesc* scene) try {
     if (!g) return RT_ERR_INVALID;
     const size_t n = g->member.size();
     std::vector<int> rc(n, RT_OK);
-    std::vector<std::thread> workers;
-    for (size_t k = 1; k < n; ++k) workers.emplace_back([&, k] { rc[k] = rt_upload_scene(g->member[k], scene); });
+    Workers workers;
+    for (size_t k = 1; k < n; ++k) workers.start([&, k] { rc[k] = rt_upload_scene(g->member[k], scene); });
     rc[0] = rt_upload_scene(g->member[0], scene);
-    for (std::thread& t : workers) t.join();
+    workers.join();
     for (size_t k = 0; k < n; ++k)
         if (rc[k] != RT_OK) return member_fail(g, k, rc[k]);
     return RT_OK;
@@ -282,6 +350,10 @@ int rt_group_render(RtGroup* g, const RtRenderParams* p, uint8_t* rgb8, RtProgre
     const uint32_t n_passes = p->samples_per_pixel / chunk;
     const int running = p->incremental != 0 || p->has_continue != 0;  // lib.rs:286
     const uint32_t first_pass = p->has_continue ? p->continue_sampling : 0;
+    // Many short passes (`incremental(1)` is what the reference's scenes ship with): a pass's samples cannot be
+    // shared out usefully, its rows can.
+    if (n_passes > 1 && static_cast<uint64_t>(chunk) * pixels_of(p) / g->member.size() < (uint64_t{1} << 25))
+        return group_render_bands(g, p, rgb8, progress, user, n_passes, chunk, first_pass);
     for (uint32_t pass = 0; pass < n_passes; ++pass) {
         const uint32_t k = pass + first_pass;  // sample_iteration, lib.rs:233-234
         const uint64_t s_begin = static_cast<uint64_t>(k) * chunk;

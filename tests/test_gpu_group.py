@@ -111,3 +111,26 @@ def test_exceptions_inside_the_library_come_back_as_status_codes(renderer, asset
     renderer.upload(s)
     # the context still renders afterwards
     assert renderer.render_sums(s.params, 0, 1).shape == (108, 192, 3)
+
+
+@pytest.mark.parametrize("members", [2, 3])
+def test_many_short_passes_are_dealt_out_as_bands_of_rows(renderer, asset_root, members):
+    """incremental(1) over several GPUs: a pass of one sample cannot be shared out, its rows can.  The
+    group cuts the frame into bands, each member renders groups of passes of the bands it pulls, and the
+    bytes are the single-GPU (and the oracle's) pass-by-pass bytes; progress is reported per pass; a
+    resumed render and a tile work the same."""
+    s = scenes.room(asset_root, w=80, h=45, spp=6, bounces=10, incremental=1)
+    cpu, _ = O.render(s, s.params, threads=4)
+    with RendererGroup([0] * members) as g:
+        g.upload(s)
+        seen = []
+        assert np.array_equal(g.render(s.params, progress=seen.append), cpu)
+        assert seen == [1, 2, 3, 4, 5, 6]
+        assert g.stats()["paths"] == 80 * 45 * 6
+        more = scenes.room(asset_root, w=80, h=45, spp=4, bounces=10, incremental=2, cont=3)
+        cpu2, _ = O.render(more, more.params, rgb8=cpu.copy(), threads=4)
+        assert np.array_equal(g.render(more.params, rgb8=cpu.copy()), cpu2)
+        t = s.params.copy()
+        t.tile_x, t.tile_y, t.tile_w, t.tile_h = 8, 5, 50, 7  # fewer rows than bands
+        cpu_t, _ = O.render(s, t, threads=4)
+        assert np.array_equal(g.render(t), cpu_t)
