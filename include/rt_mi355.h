@@ -281,7 +281,13 @@ int rt_upload_scene(RtContext* ctx, const RtSceneDesc* scene);
  * `rgb8` is the pixel area of the output image (width*height*3 bytes, or the
  * tile); it may be the mmap'd file itself.  It is read first when
  * `incremental` or `continue` is set (the running average of :286-292 uses
- * the stored bytes) and rewritten after every pass. */
+ * the stored bytes) and rewritten after every pass — or, when the passes are
+ * short (few samples of a small frame, e.g. the `incremental(1)` of the
+ * reference's shipped scenes), after every group of passes: the paths of up to
+ * 2^26 / (paths per pass) passes are traced together and the passes then
+ * finished one by one in order, which stores the same bytes several times as
+ * fast (RT_OPT_PASSES_IN_FLIGHT = 1 turns the grouping off).  `progress` is
+ * called once per pass either way. */
 int rt_render(RtContext* ctx, const RtRenderParams* params, uint8_t* rgb8,
               RtProgressFn progress, void* user);
 
@@ -438,7 +444,12 @@ RtContext* rt_group_member(RtGroup* group, uint32_t index);
 /* rt_set_option / rt_upload_scene on every member (uploads run side by side). */
 int rt_group_set_option(RtGroup* group, uint32_t option, uint64_t value);
 int rt_group_upload_scene(RtGroup* group, const RtSceneDesc* scene);
-/* rt_render over the group: same arguments, same bytes. */
+/* rt_render over the group: same arguments, same bytes.  A pass of many samples is
+ * shared out by samples (the sums handed from GPU to GPU in sample order); a render
+ * of many short passes is shared out by rows instead — bands of the region, four per
+ * GPU, pulled off a counter, each band's passes rendered by one GPU straight into its
+ * rows of `rgb8`, in groups of passes after each of which the buffer is a whole image —
+ * so that no GPU idles over a one-sample pass and nothing moves between GPUs. */
 int rt_group_render(RtGroup* group, const RtRenderParams* params, uint8_t* rgb8,
                     RtProgressFn progress, void* user);
 /* rt_render_sums over the group (`sums` is host memory): same floats. */
