@@ -239,8 +239,11 @@ typedef enum RtOption {
      * paths through all bounces (no launch, counter or barrier per bounce): 0 never, 1 whenever
      * the scene allows it (triangles traversed; spheres and planes absent or few enough to be
      * scanned where rays are created), 2 (default) then and for batches below 3 * 2^22 paths,
-     * where it is the faster loop (several times faster for previews and single-sample passes).
-     * Results do not depend on it. */
+     * where it is the faster loop (several times faster for previews and single-sample passes),
+     * and for larger batches on scenes where it measures faster: the first large batch after an
+     * upload is rendered as two halves, one through each loop, and the faster loop is kept
+     * (per-bounce launches on scenes whose rays are expensive, the one launch where most rays
+     * miss or end early).  Results do not depend on it. */
     RT_OPT_FUSED_LOOP = 17,
     RT_OPT_PASSES_IN_FLIGHT = 21, /* rt_render: passes (of `incremental` samples) whose paths are traced together before the passes are finished one by one, in order — same bytes; the image is rewritten once per such group. 0 (default) = as many as make 2^26 paths, 1 = one pass at a time */
     RT_OPT_TRACE_GUIDED = 20, /* 0/1 (default 1): a wave's reservations from the ray queue shrink as the queue runs out, so that a launch's waves finish together */

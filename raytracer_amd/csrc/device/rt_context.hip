@@ -130,7 +130,10 @@ struct RtContext {
     bool tune_share = true;  // deal pending (ray, triangle) pairs out to all lanes
     bool opt_count = false, opt_time = false, opt_fast_slab = false;
     uint32_t tune_path_group = 16384;  // paths a wave of k_path takes through all bounces at a time
-    uint32_t opt_fused = 2;  // the whole bounce loop in one launch (k_path): 0 never, 1 whenever the scene allows, 2 for batches below kFusedBelowPaths
+    uint32_t opt_fused = 2;  // the whole bounce loop in one launch (k_path): 0 never, 1 whenever the scene allows, 2 for batches below kFusedBelowPaths and, above, for scenes on which it measured faster
+    // which loop large batches of this scene and frame take when opt_fused == 2: measured once (render_sums_device)
+    enum class LargeLoop : uint8_t { Unmeasured, PerBounce, OneLaunch } large_loop = LargeLoop::Unmeasured, forced_loop = LargeLoop::Unmeasured;
+    uint64_t large_loop_key = 0;  // (bounces, pixels) the measurement belongs to
     bool debug_tallies = std::getenv("RT_MI355_DEBUG_TALLIES") != nullptr;  // slow diagnostics of the counting kernels
     uint64_t opt_samples_in_flight = 0;  // 0 = automatic
     uint64_t opt_passes_in_flight = 0;   // rt_render: passes traced together (0 = automatic, 1 = one at a time)
@@ -142,6 +145,11 @@ struct RtContext {
 };
 
 namespace {
+
+struct Timer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
 
 constexpr size_t kStatWords = 48;  // + 38 diagnostic tallies of the triangle traversal + rays traced by k_path
 constexpr size_t kStatSegments = 47;
@@ -729,7 +737,13 @@ int trace_batch(RtContext* ctx, const FrameArgs& f, const DScene& sc, uint32_t B
     // Batches below about 12 M paths run as one launch (k_path): 3.8x faster at 65 k paths, 2x at 2 M (one sample
     // of a 1080p frame), equal at 16 M.  Larger ones are faster launch by launch: shading needs far more
     // memory requests in flight than the few waves that shade at any moment inside k_path can have.
-    if (B > 0 && fused_loop_possible(ctx) && (ctx->opt_fused == 1 || (ctx->opt_fused == 2 && n_paths < kFusedBelowPaths)))
+    // Above that size the per-bounce launches win on scenes whose rays are expensive (the shading of k_path's waves has
+    // too few memory requests in flight); on scenes whose rays mostly miss or die young the one launch stays ahead
+    // (the reference's boombox frame: 21.7 against 14.5 Grays/s), so the choice for large batches is measured once
+    // per scene and frame (render_sums_device) rather than assumed.
+    const RtContext::LargeLoop large = ctx->forced_loop != RtContext::LargeLoop::Unmeasured ? ctx->forced_loop : ctx->large_loop;
+    if (B > 0 && fused_loop_possible(ctx) &&
+        (ctx->opt_fused == 1 || (ctx->opt_fused == 2 && (n_paths < kFusedBelowPaths || large == RtContext::LargeLoop::OneLaunch))))
         return render_batch_fused(ctx, f, sc, B, n_paths, n_pix, first_sample);
     // large batches run as two overlapped half-batches (not while counting: the counting kernels are slow anyway)
     const bool overlapped = ctx->n_chains > 1 && !ctx->opt_count && B > 0 && n_paths >= (1u << 21);
@@ -810,13 +824,47 @@ int render_sums_device(RtContext* ctx, const RtRenderParams* p, const Region& r,
     if (initial)
         HIP_TRY(ctx, hipMemcpyAsync(w.sums, initial, r.n_pixels * 3 * sizeof(float),
                                     initial_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
-    for (uint32_t b0 = 0; b0 < count; b0 += static_cast<uint32_t>(S)) {
-        const uint32_t nb = std::min<uint32_t>(static_cast<uint32_t>(S), count - b0);
-        rc = trace_batch(ctx, f, sc, B, n_pix, static_cast<unsigned long long>(s_begin) + b0, nb);
-        if (rc) return rc;
+    uint32_t b0 = 0;
+    auto batch = [&](uint32_t nb) -> int {
+        const int r = trace_batch(ctx, f, sc, B, n_pix, static_cast<unsigned long long>(s_begin) + b0, nb);
+        if (r) return r;
         hipLaunchKernelGGL(k_fold, dim3((n_pix + 255) / 256), dim3(256), 0, ctx->stream, w.result, w.sums, n_pix, nb,
                            b0 == 0 && !initial ? 1 : 0);
         HIP_TRY(ctx, hipGetLastError());
+        b0 += nb;
+        return RT_OK;
+    };
+    // Which loop do large batches of this scene and frame take?  Measured once: the first batch is rendered as two
+    // halves, one through each loop (both are the product's loops and give the same bits, so nothing is thrown away),
+    // each of at least 2^25 paths so that the comparison is one of large batches; the faster loop is kept until the
+    // scene, the bounce limit or the region's size changes.  The one launch must win by 3 % to be chosen.
+    const uint64_t key = (static_cast<uint64_t>(B) << 40) ^ r.n_pixels;
+    if (ctx->large_loop_key != key) {
+        ctx->large_loop_key = key;
+        ctx->large_loop = RtContext::LargeLoop::Unmeasured;
+    }
+    const uint32_t first_batch = std::min<uint32_t>(static_cast<uint32_t>(S), count);
+    if (ctx->opt_fused == 2 && ctx->large_loop == RtContext::LargeLoop::Unmeasured && B > 0 && fused_loop_possible(ctx) &&
+        first_batch >= 2 && static_cast<uint64_t>(first_batch / 2) * r.n_pixels >= (uint64_t{1} << 25)) {
+        const uint32_t half = first_batch / 2;
+        double ms[2] = {0.0, 0.0};
+        const RtContext::LargeLoop loops[2] = {RtContext::LargeLoop::PerBounce, RtContext::LargeLoop::OneLaunch};
+        for (int k = 0; k < 2; ++k) {
+            ctx->forced_loop = loops[k];
+            Timer timer;  // (trace_batch returns with the batch's stream drained)
+            rc = batch(half);
+            ctx->forced_loop = RtContext::LargeLoop::Unmeasured;
+            if (rc) return rc;
+            ms[k] = timer.ms();
+        }
+        ctx->large_loop = ms[1] < 0.97 * ms[0] ? RtContext::LargeLoop::OneLaunch : RtContext::LargeLoop::PerBounce;
+        if (ctx->debug_tallies)
+            std::fprintf(stderr, "[rt_mi355] large batches: per-bounce launches %.1f ms, one launch %.1f ms for %u samples each -> %s\n", ms[0],
+                         ms[1], half, ctx->large_loop == RtContext::LargeLoop::OneLaunch ? "one launch" : "per-bounce launches");
+    }
+    while (b0 < count) {
+        rc = batch(std::min<uint32_t>(static_cast<uint32_t>(S), count - b0));
+        if (rc) return rc;
     }
     return RT_OK;
 }
@@ -942,10 +990,6 @@ int quantize_device(RtContext* ctx, const float* d_sums, size_t n_pixels, uint32
     return RT_OK;
 }
 
-struct Timer {
-    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-    double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
-};
 
 int require_scene(RtContext* ctx) {
     if (!ctx) return RT_ERR_INVALID;
@@ -1188,6 +1232,8 @@ int rt_upload_scene(RtContext* ctx, const RtSceneDesc* s) try {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     free_scene(ctx);
     ctx->pending_samples = 0;  // samples traced against the previous scene are not folded into a new one's sums
+    ctx->large_loop = RtContext::LargeLoop::Unmeasured;
+    ctx->large_loop_key = 0;
 
     // ---- validation of everything a kernel indexes with
     if ((s->n_spheres && !s->spheres) || (s->n_planes && !s->planes) || (s->n_triangles && !s->triangles) ||
