@@ -623,8 +623,10 @@ def main() -> None:
         # ... and larger ones too where the library measured that loop to be the faster one for this scene (a few timed
         # launches per step instead of two per bounce and chain)
         one_launch = one_launch or (not tiled and st["trace_launches"] <= 4 * args.steps)
-        if one_launch:
-            rec = None
+        kernel_rec = None
+        if rec is not None:
+            kernel_rec = rec.get("path") if one_launch else rec.get("trace")
+        rec = {"trace": kernel_rec} if kernel_rec else None  # (the fields below are read from the dominant kernel's record)
         # The traversal kernel's working set (branch records, triangles) lives in LDS, L2 and the
         # Infinity Cache, so HBM does not bound it; vector-instruction issue does.  Roof: every SIMD
         # issuing one wave64 vector instruction per 2 cycles at 2.4 GHz.  Instructions per ray come from

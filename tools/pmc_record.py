@@ -107,8 +107,12 @@ def main():
     steps = line["steps"] + line["warmup"] + (1 if line.get("image_repeats") is not None else 0)
     rays = rays_per_step * steps
     fast = "fast slab" in line["config"].get("arithmetic", "")
-    trace = max((k for k in tot if "k_trace<2, false" in k), key=lambda k: tot[k].get("SQ_INSTS_VALU", 0))
-    shade = next(k for k in tot if "k_shade" in k)
+    traces = [k for k in tot if "k_trace<2, false" in k]
+    trace = max(traces, key=lambda k: tot[k].get("SQ_INSTS_VALU", 0)) if traces else None
+    shade = next((k for k in tot if "k_shade" in k), None)
+    # the one-launch bounce loop, where the run went through it (bench.py --opt FUSED_LOOP=1, or the library's own choice)
+    paths = [k for k in tot if "k_path<" in k]
+    path = max(paths, key=lambda k: tot[k].get("SQ_INSTS_VALU", 0)) if paths else None
     args = line["bench_args"]
     key = f"{args['workload']}:{args['width']}x{args['height']}:b{args['bounces']}:d{args['detail']}:fast{int(fast)}"
     if args.get("fast_build"):
@@ -121,15 +125,18 @@ def main():
     h = kernel_source_hash()
     if rec.get("source_hash") != h:
         rec = {"source_hash": h, "workloads": {}}
-    rec["workloads"][key] = {
-        "bench_args": args, "rays_per_step": rays_per_step, "steps_per_pass": steps,
-        "trace_kernel": trace, "trace": kernel_record(tot[trace], calls[trace], rays),
-        "shade": kernel_record(tot[shade], calls[shade], rays),
-    }
+    entry = rec["workloads"].get(key, {})
+    entry.update({"bench_args": args, "rays_per_step": rays_per_step, "steps_per_pass": steps})
+    if path and (not trace or tot[path].get("SQ_INSTS_VALU", 0) > tot[trace].get("SQ_INSTS_VALU", 0)):
+        entry.update({"path_kernel": path, "path": kernel_record(tot[path], calls[path], rays)})
+    else:
+        entry.update({"trace_kernel": trace, "trace": kernel_record(tot[trace], calls[trace], rays),
+                      "shade": kernel_record(tot[shade], calls[shade], rays)})
+    rec["workloads"][key] = entry
     with open(out_path, "w") as f:
         json.dump(rec, f, indent=1)
         f.write("\n")
-    print(json.dumps(rec["workloads"][key], indent=1))
+    print(json.dumps(rec["workloads"][key], indent=1)[:3000])
 
 
 if __name__ == "__main__":
