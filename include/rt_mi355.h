@@ -240,8 +240,8 @@ typedef enum RtOption {
      * the scene allows it (triangles traversed; spheres and planes absent or few enough to be
      * scanned where rays are created), 2 (default) then and for batches below 3 * 2^22 paths,
      * where it is the faster loop (several times faster for previews and single-sample passes),
-     * and for larger batches on scenes where it measures faster: the first large batch after an
-     * upload is rendered as two halves, one through each loop, and the faster loop is kept
+     * and for larger batches on scenes where it measures faster: the first two large batches after
+     * an upload are each rendered as two halves, one through each loop, and the faster loop is kept
      * (per-bounce launches on scenes whose rays are expensive, the one launch where most rays
      * miss or end early).  Results do not depend on it. */
     RT_OPT_FUSED_LOOP = 17,

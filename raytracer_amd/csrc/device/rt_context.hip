@@ -134,6 +134,8 @@ struct RtContext {
     // which loop large batches of this scene and frame take when opt_fused == 2: measured once (render_sums_device)
     enum class LargeLoop : uint8_t { Unmeasured, PerBounce, OneLaunch } large_loop = LargeLoop::Unmeasured, forced_loop = LargeLoop::Unmeasured;
     uint64_t large_loop_key = 0;  // (bounces, pixels) the measurement belongs to
+    uint32_t pilot_phase = 0;     // large batches measured so far (two decide)
+    double pilot_ms_per_sample[2] = {0.0, 0.0};  // best time of the per-bounce launches / of the one launch
     bool debug_tallies = std::getenv("RT_MI355_DEBUG_TALLIES") != nullptr;  // slow diagnostics of the counting kernels
     uint64_t opt_samples_in_flight = 0;  // 0 = automatic
     uint64_t opt_passes_in_flight = 0;   // rt_render: passes traced together (0 = automatic, 1 = one at a time)
@@ -834,33 +836,42 @@ int render_sums_device(RtContext* ctx, const RtRenderParams* p, const Region& r,
         b0 += nb;
         return RT_OK;
     };
-    // Which loop do large batches of this scene and frame take?  Measured once: the first batch is rendered as two
-    // halves, one through each loop (both are the product's loops and give the same bits, so nothing is thrown away),
-    // each of at least 2^25 paths so that the comparison is one of large batches; the faster loop is kept until the
-    // scene, the bounce limit or the region's size changes.  The one launch must win by 3 % to be chosen.
+    // Which loop do large batches of this scene and frame take?  Measured: the first two large batches are each
+    // rendered as two halves, one through each loop (both are the product's loops and give the same bits, so nothing
+    // is thrown away) — per-bounce launches first in the first batch, the one launch first in the second, so that
+    // what a first batch pays once (fresh queues, first launches) falls on each loop once — every half of at least
+    // 2^25 paths so that the comparison is one of large batches.  Each loop's better time per sample decides, and
+    // the one launch must win by 8 % to be chosen; the choice holds until the scene, the bounce limit or the region's
+    // size changes.
     const uint64_t key = (static_cast<uint64_t>(B) << 40) ^ r.n_pixels;
     if (ctx->large_loop_key != key) {
         ctx->large_loop_key = key;
         ctx->large_loop = RtContext::LargeLoop::Unmeasured;
+        ctx->pilot_phase = 0;
+        ctx->pilot_ms_per_sample[0] = ctx->pilot_ms_per_sample[1] = 0.0;
     }
     const uint32_t first_batch = std::min<uint32_t>(static_cast<uint32_t>(S), count);
     if (ctx->opt_fused == 2 && ctx->large_loop == RtContext::LargeLoop::Unmeasured && B > 0 && fused_loop_possible(ctx) &&
         first_batch >= 2 && static_cast<uint64_t>(first_batch / 2) * r.n_pixels >= (uint64_t{1} << 25)) {
         const uint32_t half = first_batch / 2;
-        double ms[2] = {0.0, 0.0};
-        const RtContext::LargeLoop loops[2] = {RtContext::LargeLoop::PerBounce, RtContext::LargeLoop::OneLaunch};
         for (int k = 0; k < 2; ++k) {
-            ctx->forced_loop = loops[k];
+            const int loop = (k + static_cast<int>(ctx->pilot_phase)) & 1;  // 0 = per-bounce launches, 1 = one launch
+            ctx->forced_loop = loop ? RtContext::LargeLoop::OneLaunch : RtContext::LargeLoop::PerBounce;
             Timer timer;  // (trace_batch returns with the batch's stream drained)
             rc = batch(half);
             ctx->forced_loop = RtContext::LargeLoop::Unmeasured;
             if (rc) return rc;
-            ms[k] = timer.ms();
+            const double ms = timer.ms() / half;
+            double& best = ctx->pilot_ms_per_sample[loop];
+            best = best > 0.0 ? std::min(best, ms) : ms;
         }
-        ctx->large_loop = ms[1] < 0.97 * ms[0] ? RtContext::LargeLoop::OneLaunch : RtContext::LargeLoop::PerBounce;
-        if (ctx->debug_tallies)
-            std::fprintf(stderr, "[rt_mi355] large batches: per-bounce launches %.1f ms, one launch %.1f ms for %u samples each -> %s\n", ms[0],
-                         ms[1], half, ctx->large_loop == RtContext::LargeLoop::OneLaunch ? "one launch" : "per-bounce launches");
+        if (++ctx->pilot_phase == 2) {
+            const double* ms = ctx->pilot_ms_per_sample;
+            ctx->large_loop = ms[1] < 0.92 * ms[0] ? RtContext::LargeLoop::OneLaunch : RtContext::LargeLoop::PerBounce;
+            if (ctx->debug_tallies)
+                std::fprintf(stderr, "[rt_mi355] large batches: per-bounce launches %.3f ms per sample, one launch %.3f -> %s\n", ms[0], ms[1],
+                             ctx->large_loop == RtContext::LargeLoop::OneLaunch ? "one launch" : "per-bounce launches");
+        }
     }
     while (b0 < count) {
         rc = batch(std::min<uint32_t>(static_cast<uint32_t>(S), count - b0));
@@ -1233,7 +1244,7 @@ int rt_upload_scene(RtContext* ctx, const RtSceneDesc* s) try {
     free_scene(ctx);
     ctx->pending_samples = 0;  // samples traced against the previous scene are not folded into a new one's sums
     ctx->large_loop = RtContext::LargeLoop::Unmeasured;
-    ctx->large_loop_key = 0;
+    ctx->large_loop_key = 0;  // (the next render starts the measurement afresh)
 
     // ---- validation of everything a kernel indexes with
     if ((s->n_spheres && !s->spheres) || (s->n_planes && !s->planes) || (s->n_triangles && !s->triangles) ||

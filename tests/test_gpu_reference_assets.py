@@ -36,15 +36,16 @@ def test_boombox_with_the_camera_of_the_reference_scene(renderer, staged):
 
 
 def test_large_batches_of_a_frame_of_mostly_misses_through_whichever_loop_measures_faster(renderer, staged):
-    """A batch of 2^26 paths of the reference's boombox frame: the first large batch after an upload is rendered
-    as two halves, one through each bounce loop, and the faster loop is kept (here the one launch: 19 of 20 rays
+    """A batch of 2^26 paths of the reference's boombox frame: the first two large batches after an upload are each
+    rendered as two halves, one through each bounce loop, and the faster loop is kept (here the one launch: 19 of 20 rays
     miss).  Whatever is chosen, the sums are those of the per-bounce loop and of the one-launch loop, bit for bit,
     on the first render (which measures) and on the second (which uses the choice), and the oracle's on a tile."""
     s = parse(assets.reference_scene_text("boombox_4k", 1024, 1024, 64, 10), staged)
     renderer.upload(s)
     first = renderer.render_sums(s.params, 0, 64)   # measures: halves of 2^25 paths through either loop
-    second = renderer.render_sums(s.params, 0, 64)  # renders with the choice
-    assert np.array_equal(bits(first), bits(second))
+    second = renderer.render_sums(s.params, 0, 64)  # measures again, the loops in the other order
+    third = renderer.render_sums(s.params, 0, 64)   # renders with the choice
+    assert np.array_equal(bits(first), bits(second)) and np.array_equal(bits(first), bits(third))
     for forced in (0, 1):
         renderer.set_option(F.RT_OPT_FUSED_LOOP, forced)
         try:
