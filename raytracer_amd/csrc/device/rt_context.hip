@@ -808,6 +808,52 @@ int workspace_for_samples(RtContext* ctx, const Region& r, uint32_t count, uint3
     return rc;
 }
 
+// Which loop do large batches of this scene and frame take?  Measured: the first two large batches are each
+// rendered as two halves, one through each loop (both are the product's loops and give the same bits, so nothing
+// is thrown away) — per-bounce launches first in the first batch, the one launch first in the second, so that
+// what a first batch pays once (fresh queues, first launches) falls on each loop once — every half of at least
+// 2^24 paths, above the size at which the one launch wins anyway.  Each loop's better time per sample decides, and
+// the one launch must win by 8 % to be chosen; the choice holds until the scene, the bounce limit or the region's
+// size changes.
+//
+// `first_batch`: samples the caller's next batch would take; `unit`: the halves are multiples of this many samples
+// (a pass's samples where passes are finished one by one); `batch(n)`: traces the next n samples and does whatever
+// the caller does with a traced batch.  When a measurement is due and the batch is large enough, the two halves are
+// rendered here; otherwise nothing happens and the caller goes on as usual.
+template <class Batch>
+int measure_large_loop(RtContext* ctx, const Region& r, uint32_t B, uint32_t first_batch, uint32_t unit, Batch&& batch) {
+    const uint64_t key = (static_cast<uint64_t>(B) << 40) ^ r.n_pixels;
+    if (ctx->large_loop_key != key) {
+        ctx->large_loop_key = key;
+        ctx->large_loop = RtContext::LargeLoop::Unmeasured;
+        ctx->pilot_phase = 0;
+        ctx->pilot_ms_per_sample[0] = ctx->pilot_ms_per_sample[1] = 0.0;
+    }
+    const uint32_t half = first_batch / 2 / unit * unit;
+    if (ctx->opt_fused != 2 || ctx->large_loop != RtContext::LargeLoop::Unmeasured || B == 0 || !fused_loop_possible(ctx) || half == 0 ||
+        static_cast<uint64_t>(half) * r.n_pixels < (uint64_t{1} << 24))
+        return RT_OK;
+    for (int k = 0; k < 2; ++k) {
+        const int loop = (k + static_cast<int>(ctx->pilot_phase)) & 1;  // 0 = per-bounce launches, 1 = one launch
+        ctx->forced_loop = loop ? RtContext::LargeLoop::OneLaunch : RtContext::LargeLoop::PerBounce;
+        Timer timer;  // (trace_batch returns with the batch's stream drained)
+        const int rc = batch(half);
+        ctx->forced_loop = RtContext::LargeLoop::Unmeasured;
+        if (rc) return rc;
+        const double ms = timer.ms() / half;
+        double& best = ctx->pilot_ms_per_sample[loop];
+        best = best > 0.0 ? std::min(best, ms) : ms;
+    }
+    if (++ctx->pilot_phase == 2) {
+        const double* ms = ctx->pilot_ms_per_sample;
+        ctx->large_loop = ms[1] < 0.92 * ms[0] ? RtContext::LargeLoop::OneLaunch : RtContext::LargeLoop::PerBounce;
+        if (ctx->debug_tallies)
+            std::fprintf(stderr, "[rt_mi355] large batches: per-bounce launches %.3f ms per sample, one launch %.3f -> %s\n", ms[0], ms[1],
+                         ctx->large_loop == RtContext::LargeLoop::OneLaunch ? "one launch" : "per-bounce launches");
+    }
+    return RT_OK;
+}
+
 // The bounce loop over samples [s_begin, s_begin + count) of the region into
 // the workspace's running sums (lib.rs:260-279 for every pixel).
 // `initial` (optional): the fold of the samples before s_begin, which the fold goes on from.
@@ -836,43 +882,9 @@ int render_sums_device(RtContext* ctx, const RtRenderParams* p, const Region& r,
         b0 += nb;
         return RT_OK;
     };
-    // Which loop do large batches of this scene and frame take?  Measured: the first two large batches are each
-    // rendered as two halves, one through each loop (both are the product's loops and give the same bits, so nothing
-    // is thrown away) — per-bounce launches first in the first batch, the one launch first in the second, so that
-    // what a first batch pays once (fresh queues, first launches) falls on each loop once — every half of at least
-    // 2^25 paths so that the comparison is one of large batches.  Each loop's better time per sample decides, and
-    // the one launch must win by 8 % to be chosen; the choice holds until the scene, the bounce limit or the region's
-    // size changes.
-    const uint64_t key = (static_cast<uint64_t>(B) << 40) ^ r.n_pixels;
-    if (ctx->large_loop_key != key) {
-        ctx->large_loop_key = key;
-        ctx->large_loop = RtContext::LargeLoop::Unmeasured;
-        ctx->pilot_phase = 0;
-        ctx->pilot_ms_per_sample[0] = ctx->pilot_ms_per_sample[1] = 0.0;
-    }
-    const uint32_t first_batch = std::min<uint32_t>(static_cast<uint32_t>(S), count);
-    if (ctx->opt_fused == 2 && ctx->large_loop == RtContext::LargeLoop::Unmeasured && B > 0 && fused_loop_possible(ctx) &&
-        first_batch >= 2 && static_cast<uint64_t>(first_batch / 2) * r.n_pixels >= (uint64_t{1} << 25)) {
-        const uint32_t half = first_batch / 2;
-        for (int k = 0; k < 2; ++k) {
-            const int loop = (k + static_cast<int>(ctx->pilot_phase)) & 1;  // 0 = per-bounce launches, 1 = one launch
-            ctx->forced_loop = loop ? RtContext::LargeLoop::OneLaunch : RtContext::LargeLoop::PerBounce;
-            Timer timer;  // (trace_batch returns with the batch's stream drained)
-            rc = batch(half);
-            ctx->forced_loop = RtContext::LargeLoop::Unmeasured;
-            if (rc) return rc;
-            const double ms = timer.ms() / half;
-            double& best = ctx->pilot_ms_per_sample[loop];
-            best = best > 0.0 ? std::min(best, ms) : ms;
-        }
-        if (++ctx->pilot_phase == 2) {
-            const double* ms = ctx->pilot_ms_per_sample;
-            ctx->large_loop = ms[1] < 0.92 * ms[0] ? RtContext::LargeLoop::OneLaunch : RtContext::LargeLoop::PerBounce;
-            if (ctx->debug_tallies)
-                std::fprintf(stderr, "[rt_mi355] large batches: per-bounce launches %.3f ms per sample, one launch %.3f -> %s\n", ms[0], ms[1],
-                             ctx->large_loop == RtContext::LargeLoop::OneLaunch ? "one launch" : "per-bounce launches");
-        }
-    }
+    // the first large batches of a scene and frame also measure which loop suits them (measure_large_loop)
+    rc = measure_large_loop(ctx, r, B, std::min<uint32_t>(static_cast<uint32_t>(S), count), 1u, batch);
+    if (rc) return rc;
     while (b0 < count) {
         rc = batch(std::min<uint32_t>(static_cast<uint32_t>(S), count - b0));
         if (rc) return rc;
@@ -1605,16 +1617,27 @@ int rt_render(RtContext* ctx, const RtRenderParams* p, uint8_t* rgb8, RtProgress
             together = 1;
         } else {
             ctx->pending_samples = 0;  // the result array is about to be overwritten
-            rc = trace_batch(ctx, frame_args(p, r), device_scene(ctx), p->max_bounces, n_pix, static_cast<unsigned long long>(k) * chunk,
-                             together * chunk);
+            // `n` samples (whole passes) from pass k + done on: traced together, then finished pass by pass
+            uint32_t done = 0;
+            auto passes = [&](uint32_t n) -> int {
+                const uint32_t n_now = n / chunk;
+                int e = trace_batch(ctx, frame_args(p, r), device_scene(ctx), p->max_bounces, n_pix,
+                                    (static_cast<unsigned long long>(k) + done) * chunk, n);
+                if (e) return e;
+                for (uint32_t j = 0; j < n_now; ++j) {
+                    hipLaunchKernelGGL(k_fold, dim3((n_pix + 255) / 256), dim3(256), 0, ctx->stream,
+                                       ctx->ws.result + static_cast<size_t>(j) * chunk * n_pix, ctx->ws.sums, n_pix, chunk, 1);
+                    HIP_TRY(ctx, hipGetLastError());
+                    e = quantize_device(ctx, ctx->ws.sums, r.n_pixels, chunk, running, k + done + j);
+                    if (e) return e;
+                }
+                done += n_now;
+                return RT_OK;
+            };
+            rc = measure_large_loop(ctx, r, p->max_bounces, together * chunk, chunk, passes);
             if (rc) return rc;
-            for (uint32_t j = 0; j < together; ++j) {
-                hipLaunchKernelGGL(k_fold, dim3((n_pix + 255) / 256), dim3(256), 0, ctx->stream,
-                                   ctx->ws.result + static_cast<size_t>(j) * chunk * n_pix, ctx->ws.sums, n_pix, chunk, 1);
-                HIP_TRY(ctx, hipGetLastError());
-                rc = quantize_device(ctx, ctx->ws.sums, r.n_pixels, chunk, running, k + j);
-                if (rc) return rc;
-            }
+            if (done < together) rc = passes((together - done) * chunk);
+            if (rc) return rc;
         }
         // the image file is readable after every group of passes (live preview)
         HIP_TRY(ctx, hipMemcpyAsync(rgb8, ctx->ws.rgb8, r.n_pixels * 3, hipMemcpyDeviceToHost, ctx->stream));
