@@ -40,4 +40,41 @@ with Renderer(0) as r:
     # the loops agree with each other on the samples they share
     r.set_option(F.RT_OPT_FUSED_LOOP, 0)
     assert np.array_equal(r.render_sums(scene.params, 3, 4).view(np.uint32), ref["one launch"])
+
+    # short passes: rt_render traces the paths of several passes together and finishes them in order; the
+    # loop is the library's own choice (measured on the first large batches after an upload)
+    r.set_option(F.RT_OPT_FUSED_LOOP, 2)
+    r.set_option(F.RT_OPT_CHAINS, 2)
+    p = scene.params.copy()
+    p.samples_per_pixel, p.incremental = 24, 1
+    want = None
+    for k in range(rounds):
+        r.upload(scene)  # (forgets the measured loop: every round measures again)
+        got = r.render(p)
+        if want is None:
+            r.set_option(F.RT_OPT_PASSES_IN_FLIGHT, 1)
+            want = r.render(p)  # one pass at a time
+            r.set_option(F.RT_OPT_PASSES_IN_FLIGHT, 0)
+        if not np.array_equal(got, want):
+            print(f"short passes, round {k}: {np.count_nonzero(got != want)} bytes differ", flush=True)
+            sys.exit(1)
+    print(f"short passes ok ({time.time() - t0:.0f} s)", flush=True)
+
+# the same frame over a list of GPUs (here: this GPU twice): bands of rows for short passes, samples dealt out for long ones
+from raytracer_amd.renderer import RendererGroup  # noqa: E402
+
+with RendererGroup([0, 0]) as g:
+    g.upload(scene)
+    for k in range(max(2, rounds // 3)):
+        if not np.array_equal(g.render(p), want):
+            print(f"group, short passes, round {k}: bytes differ", flush=True)
+            sys.exit(1)
+    long_pass = scene.params.copy()
+    long_pass.samples_per_pixel, long_pass.incremental = 32, 0
+    first = g.render(long_pass)
+    for k in range(max(2, rounds // 3)):
+        if not np.array_equal(g.render(long_pass), first):
+            print(f"group, one long pass, round {k}: bytes differ", flush=True)
+            sys.exit(1)
+    print(f"group ok ({time.time() - t0:.0f} s)", flush=True)
 print("soak ok")
