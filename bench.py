@@ -619,7 +619,7 @@ def main() -> None:
         # batches below 3 * 2^22 paths run as one launch of k_path (the library's own rule); the counter
         # record describes k_trace, so no fraction is quoted for such a run
         pixels = (params.tile_w * params.tile_h) if params.tile_w else params.width * params.height
-        one_launch = not tiled and pixels * min(args.spp, max(1, (1 << 28) // pixels)) < (3 << 22)
+        one_launch = not tiled and pixels * min(args.spp, max(1, (1 << 29) // pixels)) < (3 << 22)
         # ... and larger ones too where the library measured that loop to be the faster one for this scene (a few timed
         # launches per step instead of two per bounce and chain)
         one_launch = one_launch or (not tiled and st["trace_launches"] <= 4 * args.steps)
